@@ -1,0 +1,97 @@
+// CPython extension `_tca_pyext`: hot paths of the Python codec that cannot be
+// expressed as numpy vector operations (variable-length BYTES tensors).
+//
+//   pack_bytes(seq_of_bytes) -> bytes          K7 on the host
+//   unpack_bytes(buffer, count) -> list[bytes] K8 on the host (count < 0: all)
+//
+// The reference does both with a per-element Python loop
+// (`tritonclient/utils/__init__.py:227-246,267-276`).
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+
+#include <cstdint>
+#include <cstring>
+
+static PyObject* PackBytes(PyObject*, PyObject* arg) {
+  PyObject* seq = PySequence_Fast(arg, "pack_bytes expects a sequence of bytes objects");
+  if (!seq) return nullptr;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+  PyObject** items = PySequence_Fast_ITEMS(seq);
+  Py_ssize_t total = 4 * n;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    if (!PyBytes_Check(items[i])) {
+      Py_DECREF(seq);
+      PyErr_SetString(PyExc_TypeError, "pack_bytes: every element must be a bytes object");
+      return nullptr;
+    }
+    const Py_ssize_t len = PyBytes_GET_SIZE(items[i]);
+    if (len > static_cast<Py_ssize_t>(UINT32_MAX)) {
+      Py_DECREF(seq);
+      PyErr_SetString(PyExc_OverflowError, "pack_bytes: element longer than 4 GiB");
+      return nullptr;
+    }
+    total += len;
+  }
+  PyObject* out = PyBytes_FromStringAndSize(nullptr, total);
+  if (!out) { Py_DECREF(seq); return nullptr; }
+  uint8_t* p = reinterpret_cast<uint8_t*>(PyBytes_AS_STRING(out));
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    const uint32_t len = static_cast<uint32_t>(PyBytes_GET_SIZE(items[i]));
+    p[0] = static_cast<uint8_t>(len);
+    p[1] = static_cast<uint8_t>(len >> 8);
+    p[2] = static_cast<uint8_t>(len >> 16);
+    p[3] = static_cast<uint8_t>(len >> 24);
+    std::memcpy(p + 4, PyBytes_AS_STRING(items[i]), len);
+    p += 4 + len;
+  }
+  Py_DECREF(seq);
+  return out;
+}
+
+static PyObject* UnpackBytes(PyObject*, PyObject* args) {
+  Py_buffer view;
+  long long count = -1;
+  if (!PyArg_ParseTuple(args, "y*|L", &view, &count)) return nullptr;
+  const uint8_t* buf = static_cast<const uint8_t*>(view.buf);
+  const size_t size = static_cast<size_t>(view.len);
+  PyObject* list = PyList_New(0);
+  if (!list) { PyBuffer_Release(&view); return nullptr; }
+  size_t pos = 0;
+  long long seen = 0;
+  while (count < 0 ? pos < size : seen < count) {
+    if (pos + 4 > size) goto malformed;
+    {
+      const uint32_t len = static_cast<uint32_t>(buf[pos]) | (static_cast<uint32_t>(buf[pos + 1]) << 8) |
+                           (static_cast<uint32_t>(buf[pos + 2]) << 16) | (static_cast<uint32_t>(buf[pos + 3]) << 24);
+      pos += 4;
+      if (len > size - pos) goto malformed;
+      PyObject* item = PyBytes_FromStringAndSize(reinterpret_cast<const char*>(buf + pos), len);
+      if (!item || PyList_Append(list, item) < 0) {
+        Py_XDECREF(item);
+        Py_DECREF(list);
+        PyBuffer_Release(&view);
+        return nullptr;
+      }
+      Py_DECREF(item);
+      pos += len;
+      ++seen;
+    }
+  }
+  PyBuffer_Release(&view);
+  return list;
+malformed:
+  Py_DECREF(list);
+  PyBuffer_Release(&view);
+  PyErr_SetString(PyExc_ValueError, "malformed BYTES tensor: element overruns the buffer");
+  return nullptr;
+}
+
+static PyMethodDef kMethods[] = {
+    {"pack_bytes", PackBytes, METH_O, "Serialise a sequence of bytes objects into the BYTES wire form."},
+    {"unpack_bytes", UnpackBytes, METH_VARARGS, "Split a BYTES wire buffer into a list of bytes objects."},
+    {nullptr, nullptr, 0, nullptr}};
+
+static struct PyModuleDef kModule = {PyModuleDef_HEAD_INIT, "_tca_pyext", "native codec helpers", -1, kMethods,
+                                     nullptr, nullptr, nullptr, nullptr};
+
+PyMODINIT_FUNC PyInit__tca_pyext(void) { return PyModule_Create(&kModule); }

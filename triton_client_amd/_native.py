@@ -1,0 +1,94 @@
+"""Loader for the in-tree native libraries.
+
+``core()`` returns the ctypes handle of ``libtca_core.so`` (host side), ``hip()``
+that of ``libtca_hip.so`` (hipshm + CDNA4 kernels).  A missing library is
+compiled on first use through :mod:`triton_client_amd._build`; a library that
+cannot be built raises ``RuntimeError`` – there is no silent pure-Python
+substitute for device code.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
+
+_lock = threading.Lock()
+_core = None
+_hip = None
+
+LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
+
+
+def _ensure(target, filename):
+    path = os.path.join(LIBDIR, filename)
+    if not os.path.exists(path) or os.environ.get("TCA_REBUILD") == "1":
+        from . import _build
+
+        getattr(_build, "build_" + target)()
+    if not os.path.exists(path):
+        raise RuntimeError(f"native library {filename} is missing and could not be built")
+    return path
+
+
+def core():
+    global _core
+    if _core is not None:
+        return _core
+    with _lock:
+        if _core is not None:
+            return _core
+        lib = ctypes.CDLL(_ensure("core", "libtca_core.so"))
+        lib.tca_strerror.restype = c_char_p
+        lib.tca_strerror.argtypes = [c_int]
+        lib.tca_shm_create.restype = c_int
+        lib.tca_shm_create.argtypes = [c_char_p, c_char_p, c_uint64, POINTER(c_void_p)]
+        lib.tca_shm_attach.restype = c_int
+        lib.tca_shm_attach.argtypes = [c_char_p, c_char_p, c_uint64, c_uint64, POINTER(c_void_p)]
+        lib.tca_shm_write.restype = c_int
+        lib.tca_shm_write.argtypes = [c_void_p, c_uint64, c_uint64, c_void_p]
+        lib.tca_shm_read.restype = c_int
+        lib.tca_shm_read.argtypes = [c_void_p, c_uint64, c_uint64, c_void_p]
+        lib.tca_shm_info.restype = c_int
+        lib.tca_shm_info.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_char_p), POINTER(c_char_p),
+                                     POINTER(c_uint64), POINTER(c_uint64)]
+        lib.tca_shm_destroy.restype = c_int
+        lib.tca_shm_destroy.argtypes = [c_void_p, c_int]
+        lib.tca_bytes_index.restype = c_int64
+        lib.tca_bytes_index.argtypes = [c_void_p, c_uint64, c_int64, POINTER(c_uint64), POINTER(c_uint32), c_uint64]
+        lib.tca_fp32_to_bf16.restype = None
+        lib.tca_fp32_to_bf16.argtypes = [POINTER(c_float), POINTER(c_uint16), c_uint64]
+        lib.tca_bf16_to_fp32.restype = None
+        lib.tca_bf16_to_fp32.argtypes = [POINTER(c_uint16), POINTER(c_float), c_uint64]
+        lib.tca_base64_encode.restype = c_uint64
+        lib.tca_base64_encode.argtypes = [c_void_p, c_uint64, c_char_p, c_uint64]
+        lib.tca_base64_decode.restype = c_int64
+        lib.tca_base64_decode.argtypes = [c_char_p, c_uint64, c_void_p, c_uint64]
+        _core = lib
+    return _core
+
+
+def hip():
+    """ctypes handle of libtca_hip.so with prototypes installed by :mod:`ops._bind`."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    with _lock:
+        if _hip is not None:
+            return _hip
+        lib = ctypes.CDLL(_ensure("hip", "libtca_hip.so"))
+        from .ops import _bind
+
+        _bind.install(lib)
+        _hip = lib
+    return _hip
+
+
+def pyext_available():
+    try:
+        from ._lib import _tca_pyext  # noqa: F401
+
+        return True
+    except Exception:
+        return False
