@@ -86,7 +86,101 @@ malformed:
   return nullptr;
 }
 
+// ---------------------------------------------------------------------------
+// DLPack producer.  make_dlpack_capsule(address, type_code, bits, lanes, shape,
+// device_type, device_id, owner) -> "dltensor" capsule describing NON-owned
+// memory.  `owner` is kept alive until the consumer runs the deleter.  The
+// deleter is native code: a consumer (e.g. torch) may release its tensor while
+// the interpreter is finalising, when calling back into Python is not allowed.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct DLDevice { int32_t device_type; int32_t device_id; };
+struct DLDataType { uint8_t code; uint8_t bits; uint16_t lanes; };
+struct DLTensor {
+  void* data;
+  DLDevice device;
+  int32_t ndim;
+  DLDataType dtype;
+  int64_t* shape;
+  int64_t* strides;
+  uint64_t byte_offset;
+};
+struct DLManagedTensor {
+  DLTensor dl_tensor;
+  void* manager_ctx;
+  void (*deleter)(DLManagedTensor*);
+};
+
+struct Holder {
+  DLManagedTensor managed;
+  PyObject* owner;
+  int64_t shape[8];
+};
+
+void ManagedDeleter(DLManagedTensor* m) {
+  Holder* h = static_cast<Holder*>(m->manager_ctx);
+  if (h->owner != nullptr && Py_IsInitialized()
+#if PY_VERSION_HEX >= 0x03070000
+      && !_Py_IsFinalizing()
+#endif
+  ) {
+    PyGILState_STATE st = PyGILState_Ensure();
+    Py_DECREF(h->owner);
+    PyGILState_Release(st);
+  }
+  delete h;
+}
+
+void CapsuleDestructor(PyObject* capsule) {
+  // an unconsumed capsule still owns the managed tensor
+  if (PyCapsule_IsValid(capsule, "dltensor")) {
+    auto* m = static_cast<DLManagedTensor*>(PyCapsule_GetPointer(capsule, "dltensor"));
+    if (m && m->deleter) m->deleter(m);
+  }
+}
+
+}  // namespace
+
+static PyObject* MakeDlpackCapsule(PyObject*, PyObject* args) {
+  unsigned long long address;
+  int code, bits, lanes, device_type, device_id;
+  PyObject* shape;
+  PyObject* owner;
+  if (!PyArg_ParseTuple(args, "KiiiOiiO", &address, &code, &bits, &lanes, &shape, &device_type, &device_id, &owner))
+    return nullptr;
+  PyObject* seq = PySequence_Fast(shape, "shape must be a sequence of ints");
+  if (!seq) return nullptr;
+  const Py_ssize_t ndim = PySequence_Fast_GET_SIZE(seq);
+  if (ndim > 8) {
+    Py_DECREF(seq);
+    PyErr_SetString(PyExc_ValueError, "at most 8 dimensions are supported");
+    return nullptr;
+  }
+  Holder* h = new Holder();
+  for (Py_ssize_t i = 0; i < ndim; ++i) {
+    h->shape[i] = PyLong_AsLongLong(PySequence_Fast_GET_ITEM(seq, i));
+    if (PyErr_Occurred()) { Py_DECREF(seq); delete h; return nullptr; }
+  }
+  Py_DECREF(seq);
+  h->managed.dl_tensor.data = reinterpret_cast<void*>(static_cast<uintptr_t>(address));
+  h->managed.dl_tensor.device = DLDevice{device_type, device_id};
+  h->managed.dl_tensor.ndim = static_cast<int32_t>(ndim);
+  h->managed.dl_tensor.dtype = DLDataType{static_cast<uint8_t>(code), static_cast<uint8_t>(bits), static_cast<uint16_t>(lanes)};
+  h->managed.dl_tensor.shape = h->shape;
+  h->managed.dl_tensor.strides = nullptr;
+  h->managed.dl_tensor.byte_offset = 0;
+  h->managed.manager_ctx = h;
+  h->managed.deleter = ManagedDeleter;
+  h->owner = (owner == Py_None) ? nullptr : owner;
+  Py_XINCREF(h->owner);
+  PyObject* capsule = PyCapsule_New(&h->managed, "dltensor", CapsuleDestructor);
+  if (!capsule) { Py_XDECREF(h->owner); delete h; return nullptr; }
+  return capsule;
+}
+
 static PyMethodDef kMethods[] = {
+    {"make_dlpack_capsule", MakeDlpackCapsule, METH_VARARGS, "Wrap raw memory as a non-owning DLPack capsule."},
     {"pack_bytes", PackBytes, METH_O, "Serialise a sequence of bytes objects into the BYTES wire form."},
     {"unpack_bytes", UnpackBytes, METH_VARARGS, "Split a BYTES wire buffer into a list of bytes objects."},
     {nullptr, nullptr, 0, nullptr}};

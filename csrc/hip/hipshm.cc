@@ -1,0 +1,414 @@
+// hipshm: device shared-memory regions on HIP IPC.
+//
+// Replaces the reference's CUDA shared-memory module
+// (`tritonclient/utils/cuda_shared_memory/__init__.py:107-429`, which drives
+// cudaMalloc / cudaIpcGetMemHandle / cudaMemcpyAsync through cuda-python) with
+// a native MI355X implementation:
+//
+//   client side   hipMalloc + hipIpcGetMemHandle  -> 64-byte handle on the wire
+//   server side   hipIpcOpenMemHandle             -> zero-copy view of the region
+//
+// Differences by design:
+//  * host<->device traffic goes through a persistent, double-buffered PINNED
+//    staging ring per device (hipHostMalloc) so repeated small transfers never
+//    pay the runtime's pin/unpin path and large ones overlap memcpy with DMA;
+//  * reads copy only [offset, offset+n) (the reference always copies the whole
+//    region, `__init__.py:265-276`);
+//  * device-to-device ingestion (DLPack sources) uses hipMemcpyAsync with
+//    hipMemcpyDefault, which routes over xGMI when the source lives on a peer;
+//  * region sizes are validated against hipMemGetInfo (288 GB HBM3E per GPU);
+//  * regions are destroyed explicitly (RAII in this file), not by Python GC.
+//
+// A *host-backed* mode (env TCA_HIPSHM_FAKE=1) keeps the same ABI but places
+// regions in POSIX shared memory.  It exists so that protocol tests can run on
+// machines without a GPU; it is never selected implicitly.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int Fail(const std::string& what, hipError_t e) {
+  g_last_error = what + ": " + hipGetErrorString(e);
+  return -static_cast<int>(e) - 1000;
+}
+int FailMsg(const std::string& what, int code = -1) {
+  g_last_error = what;
+  return code;
+}
+
+#define HIP_TRY(expr, what)                           \
+  do {                                                \
+    hipError_t _e = (expr);                           \
+    if (_e != hipSuccess) return Fail((what), _e);    \
+  } while (0)
+
+bool FakeMode() {
+  static const bool fake = [] {
+    const char* v = std::getenv("TCA_HIPSHM_FAKE");
+    return v && v[0] == '1';
+  }();
+  return fake;
+}
+
+constexpr char kFakeMagic[8] = {'T', 'C', 'A', 'F', 'A', 'K', 'E', 0};
+
+// ---- per-device copy engine state ------------------------------------------
+struct DeviceCtx {
+  hipStream_t stream = nullptr;
+  void* pinned[2] = {nullptr, nullptr};
+  size_t pinned_size = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  std::mutex mu;
+};
+
+constexpr size_t kStageBytes = 8u << 20;  // per half of the ring
+
+std::mutex g_ctx_mu;
+std::unordered_map<int, DeviceCtx*> g_ctx;
+
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    ok_ = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev_ >= 0) (void)hipSetDevice(prev_);
+  }
+  bool ok() const { return ok_; }
+
+ private:
+  int prev_ = -1;
+  bool ok_ = false;
+};
+
+int GetCtx(int device, DeviceCtx** out) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  auto it = g_ctx.find(device);
+  if (it != g_ctx.end()) {
+    *out = it->second;
+    return 0;
+  }
+  DeviceGuard guard(device);
+  if (!guard.ok()) return FailMsg("hipSetDevice(" + std::to_string(device) + ") failed");
+  auto* ctx = new DeviceCtx();
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipHostMalloc(&ctx->pinned[i], kStageBytes, hipHostMallocDefault), "hipHostMalloc(staging)");
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming), "hipEventCreate");
+  }
+  ctx->pinned_size = kStageBytes;
+  g_ctx[device] = ctx;
+  *out = ctx;
+  return 0;
+}
+
+struct Region {
+  std::string name;
+  void* ptr = nullptr;
+  uint64_t size = 0;
+  int device = 0;
+  uint8_t handle[64] = {0};
+  bool fake = false;
+  bool opened = false;  // true: obtained through open(), false: owner
+  std::string fake_key;
+};
+
+std::atomic<uint64_t> g_fake_seq{0};
+
+int FakeCreate(Region* r) {
+  char key[48];
+  std::snprintf(key, sizeof(key), "/tca_hipshm_%d_%llu", static_cast<int>(getpid()),
+                static_cast<unsigned long long>(g_fake_seq.fetch_add(1)));
+  int fd = shm_open(key, O_RDWR | O_CREAT | O_EXCL, 0600);
+  if (fd < 0) return FailMsg(std::string("shm_open(fake hipshm) failed: ") + std::strerror(errno));
+  if (ftruncate(fd, static_cast<off_t>(r->size ? r->size : 1)) != 0) {
+    close(fd);
+    shm_unlink(key);
+    return FailMsg("ftruncate(fake hipshm) failed");
+  }
+  void* p = mmap(nullptr, r->size ? r->size : 1, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) {
+    shm_unlink(key);
+    return FailMsg("mmap(fake hipshm) failed");
+  }
+  r->ptr = p;
+  r->fake = true;
+  r->fake_key = key;
+  std::memset(r->handle, 0, 64);
+  std::memcpy(r->handle, kFakeMagic, 8);
+  std::strncpy(reinterpret_cast<char*>(r->handle) + 8, key, 55);
+  return 0;
+}
+
+// Chunked H2D through the pinned ring: memcpy of chunk k+1 overlaps DMA of k.
+int StagedH2D(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
+  const char* s = static_cast<const char*>(src);
+  char* d = static_cast<char*>(dst);
+  int slot = 0;
+  bool used[2] = {false, false};
+  while (n) {
+    size_t chunk = n < ctx->pinned_size ? n : ctx->pinned_size;
+    if (used[slot]) HIP_TRY(hipEventSynchronize(ctx->ev[slot]), "hipEventSynchronize");
+    std::memcpy(ctx->pinned[slot], s, chunk);
+    HIP_TRY(hipMemcpyAsync(d, ctx->pinned[slot], chunk, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D)");
+    HIP_TRY(hipEventRecord(ctx->ev[slot], ctx->stream), "hipEventRecord");
+    used[slot] = true;
+    s += chunk;
+    d += chunk;
+    n -= chunk;
+    slot ^= 1;
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+  return 0;
+}
+
+int StagedD2H(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
+  const char* s = static_cast<const char*>(src);
+  char* d = static_cast<char*>(dst);
+  // two DMA chunks in flight; drain in order
+  size_t issued = 0, drained = 0;
+  size_t sizes[2] = {0, 0};
+  int head = 0, tail = 0, inflight = 0;
+  while (drained < n) {
+    while (inflight < 2 && issued < n) {
+      size_t chunk = (n - issued) < ctx->pinned_size ? (n - issued) : ctx->pinned_size;
+      HIP_TRY(hipMemcpyAsync(ctx->pinned[head], s + issued, chunk, hipMemcpyDeviceToHost, ctx->stream),
+              "hipMemcpyAsync(D2H)");
+      HIP_TRY(hipEventRecord(ctx->ev[head], ctx->stream), "hipEventRecord");
+      sizes[head] = chunk;
+      issued += chunk;
+      head ^= 1;
+      ++inflight;
+    }
+    HIP_TRY(hipEventSynchronize(ctx->ev[tail]), "hipEventSynchronize");
+    std::memcpy(d + drained, ctx->pinned[tail], sizes[tail]);
+    drained += sizes[tail];
+    tail ^= 1;
+    --inflight;
+  }
+  return 0;
+}
+
+int CheckRange(const Region* r, uint64_t offset, uint64_t n) {
+  if (offset > r->size || n > r->size - offset)
+    return FailMsg("access of " + std::to_string(n) + " bytes at offset " + std::to_string(offset) +
+                   " is outside of region '" + r->name + "' (" + std::to_string(r->size) + " bytes)", -7);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tca_hip_last_error() { return g_last_error.c_str(); }
+
+int tca_hipshm_fake_mode() { return FakeMode() ? 1 : 0; }
+
+int tca_hip_device_count(int* n) {
+  if (FakeMode()) { *n = 1; return 0; }
+  hipError_t e = hipGetDeviceCount(n);
+  if (e != hipSuccess) { *n = 0; return Fail("hipGetDeviceCount", e); }
+  return 0;
+}
+
+int tca_hip_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (FakeMode()) { *free_bytes = *total_bytes = 288ull << 30; return 0; }
+  DeviceGuard guard(device);
+  if (!guard.ok()) return FailMsg("hipSetDevice failed");
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t), "hipMemGetInfo");
+  *free_bytes = f;
+  *total_bytes = t;
+  return 0;
+}
+
+int tca_hipshm_create(const char* name, uint64_t byte_size, int device, void** out) {
+  if (!name || !out) return FailMsg("invalid argument");
+  auto* r = new Region();
+  r->name = name;
+  r->size = byte_size;
+  r->device = device;
+  if (FakeMode()) {
+    int rc = FakeCreate(r);
+    if (rc != 0) { delete r; return rc; }
+    *out = r;
+    return 0;
+  }
+  DeviceGuard guard(device);
+  if (!guard.ok()) { delete r; return FailMsg("unable to select device " + std::to_string(device)); }
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && byte_size > free_b) {
+    delete r;
+    return FailMsg("region of " + std::to_string(byte_size) + " bytes does not fit in the " +
+                   std::to_string(free_b) + " bytes free on device " + std::to_string(device));
+  }
+  hipError_t e = hipMalloc(&r->ptr, byte_size ? byte_size : 1);
+  if (e != hipSuccess) { delete r; return Fail("hipMalloc", e); }
+  hipIpcMemHandle_t h;
+  e = hipIpcGetMemHandle(&h, r->ptr);
+  if (e != hipSuccess) {
+    (void)hipFree(r->ptr);
+    delete r;
+    return Fail("hipIpcGetMemHandle", e);
+  }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle is expected to be 64 bytes on the wire");
+  std::memcpy(r->handle, &h, 64);
+  *out = r;
+  return 0;
+}
+
+int tca_hipshm_info(void* handle, void** dev_ptr, uint8_t* raw_handle, int* device, uint64_t* byte_size, int* is_host) {
+  auto* r = static_cast<Region*>(handle);
+  if (!r) return FailMsg("null region");
+  if (dev_ptr) *dev_ptr = r->ptr;
+  if (raw_handle) std::memcpy(raw_handle, r->handle, 64);
+  if (device) *device = r->device;
+  if (byte_size) *byte_size = r->size;
+  if (is_host) *is_host = r->fake ? 1 : 0;
+  return 0;
+}
+
+// Host -> region.
+int tca_hipshm_write(void* handle, uint64_t offset, const void* src, uint64_t n) {
+  auto* r = static_cast<Region*>(handle);
+  if (!r) return FailMsg("null region");
+  int rc = CheckRange(r, offset, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (r->fake) { std::memcpy(static_cast<char*>(r->ptr) + offset, src, n); return 0; }
+  DeviceCtx* ctx = nullptr;
+  rc = GetCtx(r->device, &ctx);
+  if (rc) return rc;
+  DeviceGuard guard(r->device);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return StagedH2D(ctx, static_cast<char*>(r->ptr) + offset, src, n);
+}
+
+// Region -> host; only the requested range moves.
+int tca_hipshm_read(void* handle, uint64_t offset, void* dst, uint64_t n) {
+  auto* r = static_cast<Region*>(handle);
+  if (!r) return FailMsg("null region");
+  int rc = CheckRange(r, offset, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (r->fake) { std::memcpy(dst, static_cast<char*>(r->ptr) + offset, n); return 0; }
+  DeviceCtx* ctx = nullptr;
+  rc = GetCtx(r->device, &ctx);
+  if (rc) return rc;
+  DeviceGuard guard(r->device);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return StagedD2H(ctx, dst, static_cast<char*>(r->ptr) + offset, n);
+}
+
+// Any address the runtime can classify (device, pinned host, peer device) ->
+// region.  `src_device` < 0 means pageable/unknown host memory.
+int tca_hipshm_copy_from(void* handle, uint64_t offset, const void* src, uint64_t n, int src_device) {
+  auto* r = static_cast<Region*>(handle);
+  if (!r) return FailMsg("null region");
+  int rc = CheckRange(r, offset, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (r->fake) { std::memcpy(static_cast<char*>(r->ptr) + offset, src, n); return 0; }
+  if (src_device < 0) return tca_hipshm_write(handle, offset, src, n);
+  DeviceCtx* ctx = nullptr;
+  rc = GetCtx(r->device, &ctx);
+  if (rc) return rc;
+  DeviceGuard guard(r->device);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (src_device != r->device) {
+    int can = 0;
+    (void)hipDeviceCanAccessPeer(&can, r->device, src_device);
+    if (can) (void)hipDeviceEnablePeerAccess(src_device, 0);  // already-enabled is fine
+    (void)hipGetLastError();
+  }
+  HIP_TRY(hipMemcpyAsync(static_cast<char*>(r->ptr) + offset, src, n, hipMemcpyDefault, ctx->stream),
+          "hipMemcpyAsync(D2D)");
+  HIP_TRY(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+  return 0;
+}
+
+int tca_hipshm_destroy(void* handle) {
+  auto* r = static_cast<Region*>(handle);
+  if (!r) return FailMsg("null region");
+  int rc = 0;
+  if (r->fake) {
+    munmap(r->ptr, r->size ? r->size : 1);
+    if (!r->opened) shm_unlink(r->fake_key.c_str());
+  } else if (r->opened) {
+    DeviceGuard guard(r->device);
+    hipError_t e = hipIpcCloseMemHandle(r->ptr);
+    if (e != hipSuccess) rc = Fail("hipIpcCloseMemHandle", e);
+  } else {
+    DeviceGuard guard(r->device);
+    hipError_t e = hipFree(r->ptr);
+    if (e != hipSuccess) rc = Fail("hipFree", e);
+  }
+  delete r;
+  return rc;
+}
+
+// Server side: map a region exported by ANOTHER process.
+int tca_hipshm_open(const char* name, const uint8_t* raw_handle, uint64_t byte_size, int device, void** out) {
+  if (!raw_handle || !out) return FailMsg("invalid argument");
+  auto* r = new Region();
+  r->name = name ? name : "";
+  r->size = byte_size;
+  r->device = device;
+  r->opened = true;
+  std::memcpy(r->handle, raw_handle, 64);
+  if (std::memcmp(raw_handle, kFakeMagic, 8) == 0) {
+    if (!FakeMode()) { delete r; return FailMsg("host-backed hipshm handle received but TCA_HIPSHM_FAKE is not set"); }
+    r->fake = true;
+    r->fake_key.assign(reinterpret_cast<const char*>(raw_handle) + 8);
+    int fd = shm_open(r->fake_key.c_str(), O_RDWR, 0600);
+    if (fd < 0) { delete r; return FailMsg("unable to open host-backed hipshm region"); }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || static_cast<uint64_t>(st.st_size) < byte_size) {
+      close(fd);
+      delete r;
+      return FailMsg("registered byte_size exceeds the size of the exported region");
+    }
+    void* p = mmap(nullptr, byte_size ? byte_size : 1, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { delete r; return FailMsg("mmap of host-backed hipshm region failed"); }
+    r->ptr = p;
+    *out = r;
+    return 0;
+  }
+  if (FakeMode()) { delete r; return FailMsg("TCA_HIPSHM_FAKE is set but a real HIP IPC handle was received"); }
+  DeviceGuard guard(device);
+  if (!guard.ok()) { delete r; return FailMsg("unable to select device " + std::to_string(device)); }
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, raw_handle, 64);
+  hipError_t e = hipIpcOpenMemHandle(&r->ptr, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) { delete r; return Fail("hipIpcOpenMemHandle", e); }
+  *out = r;
+  return 0;
+}
+
+int tca_hip_device_synchronize(int device) {
+  if (FakeMode()) return 0;
+  DeviceGuard guard(device);
+  HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Host/device shared declarations for the CDNA4 kernels in this directory.
+// All launchers have C linkage and take raw device pointers plus a hipStream_t
+// (as void*), so they can be driven from C++ and from Python/ctypes alike.
+#pragma once
+
+#include <cstdint>
+
+namespace tca {
+
+// Element types understood by the kernels (values are part of the C ABI).
+enum DType : int { kF32 = 0, kF16 = 1, kBF16 = 2, kI8 = 3, kU8 = 4, kI16 = 5, kU16 = 6, kI32 = 7, kU32 = 8, kF64 = 9 };
+
+// One source image of a preprocessing batch (device-visible array).
+struct PreprocImage {
+  const uint8_t* src;  // HWC, 8 bit, device memory
+  int height;
+  int width;
+  int stride;    // bytes between rows
+  int channels;  // 1, 3 or 4
+  int bgr;       // 1: B,G,R(,A) order
+  int kx;        // taps per output column (row pitch of the x coefficient table)
+  int ky;        // taps per output row
+  int xb_off;    // index of this image's first x window in `bounds`
+  int yb_off;    // index of its first y window
+  int xk_off;    // index of its first x coefficient in `coeffs`
+  int yk_off;    // index of its first y coefficient
+  int pad_;
+};
+
+struct PreprocParams {
+  int out_h;
+  int out_w;
+  int out_c;     // 1 or 3
+  int nhwc;      // 0: NCHW planes, 1: NHWC interleaved
+  int tile_h;    // output rows per block (1..16)
+  int max_rows;  // max source rows any tile needs (sizes the LDS buffer)
+  long long image_stride;  // elements between consecutive batch entries in dst
+  float scale[4];
+  float bias[4];
+};
+
+}  // namespace tca
+
+extern "C" {
+// Fused convert+resize+normalise+layout+cast.  Returns 0 or a negative error.
+int tca_preprocess_launch(const void* images, const void* bounds, const void* coeffs, void* dst,
+                          const tca::PreprocParams* prm, int batch, int dtype, void* stream);
+
+// BYTES tensors (length-prefixed wire form).
+int tca_bytes_pack_launch(const uint8_t* payload, const uint64_t* offsets, uint64_t n, uint8_t* out,
+                          uint64_t out_bytes, void* stream);
+int tca_bytes_index_launch(const uint8_t* stream_bytes, uint64_t size, uint64_t max_elems, uint64_t* offsets,
+                           uint32_t* lens, uint64_t* status, void* stream);
+int tca_bytes_gather_launch(const uint8_t* stream_bytes, const uint64_t* offsets, const uint32_t* lens, uint64_t n,
+                            uint8_t* out, uint32_t pitch, void* stream);
+int tca_exclusive_scan_u64_launch(const uint32_t* lens, uint64_t n, uint32_t add_each, uint64_t* out,
+                                  void* stream);
+
+// BF16 <-> FP32 (truncate / round-to-nearest-even selectable).
+int tca_fp32_to_bf16_launch(const float* src, uint16_t* dst, uint64_t n, int round_nearest, void* stream);
+int tca_bf16_to_fp32_launch(const uint16_t* src, float* dst, uint64_t n, void* stream);
+
+// Classification head helpers.
+int tca_topk_launch(const void* logits, int dtype, int rows, int cols, int k, float* values, int* indices,
+                    void* stream);
+int tca_classify_strings_launch(const float* values, const int* indices, int rows, int k, const uint8_t* labels,
+                                const uint32_t* label_offsets, int num_labels, uint8_t* out, uint64_t out_cap,
+                                uint64_t* out_size, void* stream);
+}

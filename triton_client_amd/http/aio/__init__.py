@@ -103,7 +103,8 @@ class InferenceServerClient(InferenceServerClientBase):
         self._conn = aiohttp.TCPConnector(ssl=ssl_context if ssl_context is not None else (None if ssl else False),
                                           limit=conn_limit)
         self._stub = aiohttp.ClientSession(connector=self._conn, timeout=aiohttp.ClientTimeout(total=conn_timeout),
-                                           auto_decompress=False)
+                                           auto_decompress=False,
+                                           skip_auto_headers=("Accept-Encoding",))
         self._verbose = verbose
 
     async def __aenter__(self):

@@ -1,0 +1,202 @@
+"""CPU reference models the client examples and tests talk to.
+
+Contracts (reference examples, ``src/python/examples``):
+
+=============================  ==============================================
+``simple``                     INT32 add / sub of two ``[batch,16]`` tensors
+``simple_string``              same on decimal strings (BYTES)
+``simple_identity``            BYTES identity (embedded NULs survive)
+``custom_identity_int32``      INT32 identity; ``execute_delay_ms`` parameter
+``onnx_int32_int32_int32``     add/sub, versions 2 and 3 swap the outputs
+``simple_sequence`` & co.      stateful sequence models
+``repeat_int32``               decoupled: one response per input element
+=============================  ==============================================
+"""
+
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .base import ExecContext, Model, ModelError, TensorSpec, register
+
+
+def _np_bytes(values, shape):
+    out = np.empty(len(values), dtype=np.object_)
+    for i, v in enumerate(values):
+        out[i] = v
+    return out.reshape(shape)
+
+
+@register
+class Simple(Model):
+    name = "simple"
+    max_batch_size = 8
+    inputs = [TensorSpec("INPUT0", "INT32", [16]), TensorSpec("INPUT1", "INT32", [16])]
+    outputs = [TensorSpec("OUTPUT0", "INT32", [16]), TensorSpec("OUTPUT1", "INT32", [16])]
+
+    def execute(self, inputs, ctx):
+        a, b = inputs["INPUT0"], inputs["INPUT1"]
+        return {"OUTPUT0": a + b, "OUTPUT1": a - b}
+
+
+@register
+class VersionedAddSub(Model):
+    """Three versions; 2 and 3 return (sub, add) instead of (add, sub)
+    (reference ``src/c++/tests/cc_client_test.cc:436-440``)."""
+
+    name = "onnx_int32_int32_int32"
+    platform = "onnxruntime_onnx"
+    versions = ("1", "2", "3")
+    max_batch_size = 8
+    inputs = [TensorSpec("INPUT0", "INT32", [16]), TensorSpec("INPUT1", "INT32", [16])]
+    outputs = [TensorSpec("OUTPUT0", "INT32", [16]), TensorSpec("OUTPUT1", "INT32", [16])]
+
+    def execute(self, inputs, ctx):
+        a, b = inputs["INPUT0"], inputs["INPUT1"]
+        if ctx.version in ("2", "3"):
+            return {"OUTPUT0": a - b, "OUTPUT1": a + b}
+        return {"OUTPUT0": a + b, "OUTPUT1": a - b}
+
+
+@register
+class SimpleString(Model):
+    name = "simple_string"
+    max_batch_size = 8
+    inputs = [TensorSpec("INPUT0", "BYTES", [16]), TensorSpec("INPUT1", "BYTES", [16])]
+    outputs = [TensorSpec("OUTPUT0", "BYTES", [16]), TensorSpec("OUTPUT1", "BYTES", [16])]
+
+    def execute(self, inputs, ctx):
+        try:
+            a = np.array([int(x) for x in inputs["INPUT0"].reshape(-1)], dtype=np.int64)
+            b = np.array([int(x) for x in inputs["INPUT1"].reshape(-1)], dtype=np.int64)
+        except ValueError as e:
+            raise ModelError(f"simple_string expects decimal integer strings: {e}") from None
+        shape = inputs["INPUT0"].shape
+        return {
+            "OUTPUT0": _np_bytes([str(v).encode() for v in (a + b)], shape),
+            "OUTPUT1": _np_bytes([str(v).encode() for v in (a - b)], shape),
+        }
+
+
+@register
+class SimpleIdentity(Model):
+    name = "simple_identity"
+    max_batch_size = 8
+    inputs = [TensorSpec("INPUT0", "BYTES", [-1])]
+    outputs = [TensorSpec("OUTPUT0", "BYTES", [-1])]
+
+    def execute(self, inputs, ctx):
+        return {"OUTPUT0": inputs["INPUT0"]}
+
+
+@register
+class CustomIdentityInt32(Model):
+    """Identity with an optional server side delay (``execute_delay_ms``
+    parameter) – what the timeout tests rely on
+    (``src/c++/tests/client_timeout_test.cc:421``)."""
+
+    name = "custom_identity_int32"
+    max_batch_size = 1024
+    inputs = [TensorSpec("INPUT0", "INT32", [-1])]
+    outputs = [TensorSpec("OUTPUT0", "INT32", [-1])]
+
+    def execute(self, inputs, ctx):
+        delay = float(self.parameters.get("execute_delay_ms", 0) or 0)
+        delay = float(ctx.parameters.get("execute_delay_ms", delay))
+        if delay > 0:
+            time.sleep(delay / 1000.0)
+        return {"OUTPUT0": inputs["INPUT0"]}
+
+
+class _SequenceBase(Model):
+    sequence = True
+    max_batch_size = 1
+    inputs = [TensorSpec("INPUT", "INT32", [1])]
+    outputs = [TensorSpec("OUTPUT", "INT32", [1])]
+
+
+@register
+class SimpleSequence(_SequenceBase):
+    """``OUTPUT = INPUT`` (+1 on the first request of a sequence)."""
+
+    name = "simple_sequence"
+
+    def execute(self, inputs, ctx):
+        value = inputs["INPUT"].astype(np.int32)
+        if ctx.sequence is not None and ctx.sequence.start:
+            value = value + 1
+        return {"OUTPUT": value}
+
+
+def _corrid_as_int(sequence_id):
+    try:
+        return int(sequence_id)
+    except (TypeError, ValueError):
+        raise ModelError("dyna sequence models require a correlation id that decodes to an integer") from None
+
+
+@register
+class SimpleDynaSequence(_SequenceBase):
+    """Like ``simple_sequence`` and adds the correlation id on sequence end."""
+
+    name = "simple_dyna_sequence"
+
+    def execute(self, inputs, ctx):
+        value = inputs["INPUT"].astype(np.int32)
+        seq = ctx.sequence
+        if seq is not None:
+            if seq.start:
+                value = value + 1
+            if seq.end:
+                value = value + np.int32(_corrid_as_int(seq.sequence_id))
+        return {"OUTPUT": value}
+
+
+@register
+class SimpleStringDynaSequence(_SequenceBase):
+    """String correlation ids; accumulates inputs over the sequence and adds
+    the correlation id on sequence end."""
+
+    name = "simple_string_dyna_sequence"
+
+    def execute(self, inputs, ctx):
+        value = inputs["INPUT"].astype(np.int32)
+        seq = ctx.sequence
+        if seq is not None:
+            acc = seq.state.get("acc")
+            if acc is not None and not seq.start:
+                value = value + acc
+            seq.state["acc"] = value.copy()
+            if seq.end:
+                value = value + np.int32(_corrid_as_int(seq.sequence_id))
+        return {"OUTPUT": value}
+
+
+@register
+class RepeatInt32(Model):
+    """Decoupled: for ``IN[n]`` emit n responses ``OUT=[IN[i]]``, ``IDX=[i]``,
+    sleeping ``DELAY[i]`` ms before each and ``WAIT`` ms after the last."""
+
+    name = "repeat_int32"
+    decoupled = True
+    inputs = [TensorSpec("IN", "INT32", [-1]), TensorSpec("DELAY", "UINT32", [-1]), TensorSpec("WAIT", "UINT32", [1])]
+    outputs = [TensorSpec("OUT", "INT32", [1]), TensorSpec("IDX", "UINT32", [1])]
+
+    def execute(self, inputs, ctx):
+        values = inputs["IN"].reshape(-1)
+        delays = inputs["DELAY"].reshape(-1)
+        if len(values) != len(delays):
+            raise ModelError("IN and DELAY must have the same number of elements")
+        wait = int(inputs["WAIT"].reshape(-1)[0]) if "WAIT" in inputs else 0
+
+        def responses():
+            for i, v in enumerate(values):
+                if delays[i]:
+                    time.sleep(float(delays[i]) / 1000.0)
+                yield {"OUT": np.array([v], dtype=np.int32), "IDX": np.array([i], dtype=np.uint32)}
+            if wait:
+                time.sleep(wait / 1000.0)
+
+        return responses()

@@ -1,0 +1,258 @@
+"""GPU vision models: ResNet-50 (random-init, fp16, channels-last) for MI355X.
+
+The network is defined here (torchvision is not part of the image) with the
+standard bottleneck layout (3-4-6-3, stride on the 3x3 conv).  For serving:
+
+* BatchNorm is folded into the preceding convolution at load time, so the
+  executed graph is conv(+bias)+ReLU only;
+* weights are fp16 / channels-last (NHWC is what MIOpen's MFMA kernels want);
+* the whole forward is captured in a HIP graph per (batch size, input address,
+  output address) – a request whose tensors live in hipshm regions replays a
+  graph that reads the input region and writes the output region directly, so
+  there is no staging copy at all (the reference's CUDA-shm path always stages
+  through the framework's own buffers).
+
+Model contract (what ``image_client`` expects, reference
+``src/python/examples/image_client.py:59-150``): one ``FP16``/``FP32`` NCHW
+input ``[3,224,224]`` with batch dimension, one ``FP32`` vector output
+``[1000]``.
+"""
+
+from __future__ import annotations
+
+import threading
+from collections import OrderedDict
+
+from .base import Model, ModelError, TensorSpec, register
+
+_LAYERS = (3, 4, 6, 3)
+_WIDTHS = (64, 128, 256, 512)
+
+
+def _build_resnet50(torch, num_classes=1000):
+    nn = torch.nn
+
+    class ConvBN(nn.Module):
+        def __init__(self, cin, cout, k, stride=1, relu=True):
+            super().__init__()
+            self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+            self.bn = nn.BatchNorm2d(cout)
+            self.relu = relu
+
+        def forward(self, x):
+            x = self.bn(self.conv(x)) if self.bn is not None else self.conv(x)
+            return torch.relu_(x) if self.relu else x
+
+        def fold(self):
+            """Fold the BatchNorm affine transform into the convolution."""
+            bn = self.bn
+            if bn is None:
+                return
+            w = self.conv.weight
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            fused = nn.Conv2d(self.conv.in_channels, self.conv.out_channels, self.conv.kernel_size,
+                              stride=self.conv.stride, padding=self.conv.padding, bias=True)
+            fused.weight.data = (w * scale.reshape(-1, 1, 1, 1)).to(w.dtype)
+            fused.bias.data = (bn.bias - bn.running_mean * scale).to(w.dtype)
+            self.conv = fused
+            self.bn = None
+
+    class Bottleneck(nn.Module):
+        def __init__(self, cin, width, stride):
+            super().__init__()
+            cout = width * 4
+            self.a = ConvBN(cin, width, 1)
+            self.b = ConvBN(width, width, 3, stride=stride)
+            self.c = ConvBN(width, cout, 1, relu=False)
+            self.down = ConvBN(cin, cout, 1, stride=stride, relu=False) if (stride != 1 or cin != cout) else None
+
+        def forward(self, x):
+            identity = x if self.down is None else self.down(x)
+            y = self.c(self.b(self.a(x)))
+            y += identity
+            return torch.relu_(y)
+
+    class ResNet50(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = ConvBN(3, 64, 7, stride=2)
+            self.pool = nn.MaxPool2d(3, stride=2, padding=1)
+            blocks = []
+            cin = 64
+            for stage, (n, width) in enumerate(zip(_LAYERS, _WIDTHS)):
+                for i in range(n):
+                    stride = 2 if (i == 0 and stage > 0) else 1
+                    blocks.append(Bottleneck(cin, width, stride))
+                    cin = width * 4
+            self.blocks = nn.Sequential(*blocks)
+            self.fc = nn.Linear(cin, num_classes)
+
+        def features(self, x):
+            x = self.pool(self.stem(x))
+            x = self.blocks(x)
+            return x.mean(dim=(2, 3))  # global average pool -> [B, 2048]
+
+        def forward(self, x):
+            return self.fc(self.features(x))
+
+        def fold_batchnorm(self):
+            for m in self.modules():
+                if isinstance(m, ConvBN):
+                    m.fold()
+
+    return ResNet50()
+
+
+class _GraphCache:
+    """LRU of captured HIP graphs keyed by (batch, in_ptr, out_ptr)."""
+
+    def __init__(self, capacity=64):
+        self._items = OrderedDict()
+        self._capacity = capacity
+
+    def get(self, key):
+        item = self._items.get(key)
+        if item is not None:
+            self._items.move_to_end(key)
+        return item
+
+    def put(self, key, value):
+        self._items[key] = value
+        while len(self._items) > self._capacity:
+            self._items.popitem(last=False)
+
+
+@register
+class ResNet50(Model):
+    name = "resnet50"
+    platform = "pytorch_rocm"
+    backend = "pytorch"
+    device = "gpu"
+    max_batch_size = 256
+    dynamic_batching = True
+    max_queue_delay_us = 200
+    inputs = [TensorSpec("input", "FP16", [3, 224, 224], format="FORMAT_NCHW")]
+    outputs = [TensorSpec("output", "FP32", [1000], label_filename="labels.txt")]
+
+    def __init__(self):
+        super().__init__()
+        self._torch = None
+        self._net = None
+        self._graphs = _GraphCache()
+        self._lock = threading.Lock()
+        self._stream = None
+        self.labels = [f"class_{i}" for i in range(1000)]
+        self.use_graphs = True
+
+    # -- lifecycle --
+    def load(self, device_index=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise ModelError("resnet50 needs an MI355X (torch.cuda.is_available() is False)")
+        self._torch = torch
+        self._device = torch.device("cuda", device_index or 0)
+        torch.cuda.set_device(self._device)
+        gen = torch.Generator().manual_seed(0)
+        net = _build_resnet50(torch)
+        # random-init weights of the real architecture (no checkpoints offline):
+        # keep activations in a sane range so fp16 does not overflow
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.dim() > 1:
+                    fan_in = p[0].numel()
+                    p.copy_(torch.randn(p.shape, generator=gen) * (1.0 / fan_in) ** 0.5)
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_var.fill_(1.0)
+                    m.running_mean.zero_()
+        net.eval()
+        net.fold_batchnorm()
+        net = net.to(self._device, dtype=torch.float16).to(memory_format=torch.channels_last)
+        for p in net.parameters():
+            p.requires_grad_(False)
+        self._net = net
+        self._stream = torch.cuda.Stream(device=self._device)
+        torch.backends.cudnn.benchmark = True
+        # warm-up: lets MIOpen pick its kernels before the first request / capture
+        x = torch.zeros(8, 3, 224, 224, device=self._device, dtype=torch.float16)
+        with torch.no_grad(), torch.cuda.stream(self._stream):
+            for _ in range(2):
+                self._forward_eager(x)
+        self._stream.synchronize()
+
+    def unload(self):
+        self._graphs = _GraphCache()
+        self._net = None
+        if self._torch is not None:
+            self._torch.cuda.empty_cache()
+
+    # -- execution --
+    def _forward_eager(self, x):
+        torch = self._torch
+        x = x.contiguous(memory_format=torch.channels_last)
+        return self._net(x).float()
+
+    def _forward_into(self, x, out):
+        torch = self._torch
+        feats = self._net.features(x.contiguous(memory_format=torch.channels_last))
+        logits = self._net.fc(feats)
+        out.copy_(logits)  # fp16 -> fp32 cast fused into the copy kernel
+
+    def run(self, x, out=None):
+        """Forward ``x`` ([B,3,224,224] fp16 on this GPU).  When ``out`` (fp32
+        [B,1000]) is given the logits are written there.  Work is enqueued on
+        the model stream; the caller synchronises via ``self.stream``."""
+        torch = self._torch
+        batch = x.shape[0]
+        if out is None:
+            out = torch.empty(batch, 1000, device=self._device, dtype=torch.float32)
+        if not self.use_graphs:
+            with torch.no_grad(), torch.cuda.stream(self._stream):
+                self._forward_into(x, out)
+            return out
+        key = (batch, x.data_ptr(), out.data_ptr())
+        with self._lock:
+            graph = self._graphs.get(key)
+            if graph is None:
+                graph = self._capture(x, out)
+                self._graphs.put(key, graph)
+            with torch.cuda.stream(self._stream):
+                graph[0].replay()
+        return out
+
+    def _capture(self, x, out):
+        torch = self._torch
+        with torch.no_grad():
+            with torch.cuda.stream(self._stream):
+                self._forward_into(x, out)  # warm-up for this shape
+            self._stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._stream):
+                self._forward_into(x, out)
+        return (g, x, out)  # keep the tensors (hence the IPC mappings) alive
+
+    @property
+    def stream(self):
+        return self._stream
+
+    def execute(self, inputs, ctx):
+        torch = self._torch
+        x = inputs["input"]
+        if x.dtype != torch.float16:
+            x = x.to(torch.float16)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 224, 224):
+            raise ModelError(f"unexpected shape for input 'input' for model 'resnet50'. Expected [-1,3,224,224], "
+                             f"got {list(x.shape)}")
+        out = inputs.get("__out__output")  # preallocated destination (e.g. a hipshm view)
+        result = self.run(x, out)
+        return {"output": result}
+
+
+@register
+class ResNet50Fp32In(ResNet50):
+    """Same network behind an FP32 input (what stock ``image_client`` sends
+    when the model metadata says FP32)."""
+
+    name = "resnet50_fp32"
+    inputs = [TensorSpec("input", "FP32", [3, 224, 224], format="FORMAT_NCHW")]

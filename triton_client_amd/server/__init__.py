@@ -1,0 +1,166 @@
+"""Minimal KServe-v2 / Triton-protocol server used by tests, examples and the
+load generator.
+
+``Server``            in-process: HTTP on an asyncio loop thread + gRPC server
+``spawn_server``      the same in a child process (required for hipshm: a HIP
+                      IPC handle cannot be opened by the process that exported
+                      it, see the reference README's ``--pid host`` note,
+                      ``README.md:196-204``)
+
+CLI: ``python -m triton_client_amd.server --http-port 8000 --grpc-port 8001
+--gpu 0 --models simple,resnet50``
+"""
+
+from __future__ import annotations
+
+import asyncio
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+from .core import InferenceCore, ServerError  # noqa: F401
+
+
+class Server:
+    """In-process server.  ``http_port`` / ``grpc_port`` of 0 pick free ports."""
+
+    def __init__(self, models=None, gpu=None, http_port=0, grpc_port=0, host="127.0.0.1", model_control="none",
+                 enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32):
+        self.core = InferenceCore(models=models, gpu=gpu, model_control=model_control)
+        self.host = host
+        self._http_port = http_port
+        self._grpc_port = grpc_port
+        self._enable_http = enable_http
+        self._enable_grpc = enable_grpc
+        self._http_workers = http_workers
+        self._grpc_workers = grpc_workers
+        self._loop = None
+        self._thread = None
+        self.http = None
+        self.grpc = None
+
+    @property
+    def http_url(self):
+        return f"{self.host}:{self._http_port}"
+
+    @property
+    def grpc_url(self):
+        return f"{self.host}:{self._grpc_port}"
+
+    def start(self):
+        if self._enable_grpc:
+            from .grpc_front import GrpcFront
+
+            self.grpc = GrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers)
+            self._grpc_port = self.grpc.start()
+        if self._enable_http:
+            from .http_front import HttpFront
+
+            ready = threading.Event()
+            failure = []
+
+            def run():
+                loop = asyncio.new_event_loop()
+                asyncio.set_event_loop(loop)
+                self._loop = loop
+                self.http = HttpFront(self.core, self.host, self._http_port, workers=self._http_workers)
+                try:
+                    self._http_port = loop.run_until_complete(self.http.start())
+                except Exception as e:  # bind failure
+                    failure.append(e)
+                    ready.set()
+                    return
+                ready.set()
+                loop.run_forever()
+                loop.run_until_complete(self.http.stop())
+                loop.close()
+
+            self._thread = threading.Thread(target=run, name="tca-http-loop", daemon=True)
+            self._thread.start()
+            ready.wait()
+            if failure:
+                raise failure[0]
+        return self
+
+    def stop(self):
+        if self.grpc is not None:
+            self.grpc.stop()
+            self.grpc = None
+        if self._loop is not None:
+            self._loop.call_soon_threadsafe(self._loop.stop)
+            self._thread.join(timeout=5)
+            self._loop = None
+        self.core.shutdown()
+
+    def __enter__(self):
+        return self.start()
+
+    def __exit__(self, *exc):
+        self.stop()
+
+
+class ServerProcess:
+    """Handle of a server running in a child process."""
+
+    def __init__(self, proc, info):
+        self.proc = proc
+        self.info = info
+        self.http_url = f"127.0.0.1:{info['http_port']}"
+        self.grpc_url = f"127.0.0.1:{info['grpc_port']}"
+
+    def stop(self, timeout=10):
+        if self.proc.poll() is None:
+            try:
+                self.proc.stdin.close()  # the child exits when its stdin closes
+            except Exception:
+                pass
+            try:
+                self.proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                self.proc.kill()
+                self.proc.wait()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
+
+
+def spawn_server(models=None, gpu=None, http_port=0, grpc_port=0, env=None, startup_timeout=600.0, extra_args=()):
+    """Start ``python -m triton_client_amd.server`` as a child and wait until it
+    reports its ports (one JSON line on stdout)."""
+    cmd = [sys.executable, "-u", "-m", "triton_client_amd.server", "--http-port", str(http_port), "--grpc-port",
+           str(grpc_port), "--announce", "--exit-on-stdin-close"]
+    if models:
+        cmd += ["--models", ",".join(models)]
+    if gpu is not None:
+        cmd += ["--gpu", str(gpu)]
+    cmd += list(extra_args)
+    child_env = dict(os.environ)
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    child_env["PYTHONPATH"] = root + os.pathsep + child_env.get("PYTHONPATH", "")
+    if env:
+        child_env.update(env)
+    proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=child_env, cwd=root)
+    deadline = time.time() + startup_timeout
+    info = None
+    while time.time() < deadline:
+        line = proc.stdout.readline()
+        if not line:
+            if proc.poll() is not None:
+                raise RuntimeError(f"server process exited with code {proc.returncode} before becoming ready")
+            continue
+        text = line.decode("utf-8", "replace").strip()
+        if text.startswith("{") and "grpc_port" in text:
+            info = json.loads(text)
+            break
+    if info is None:
+        proc.kill()
+        raise RuntimeError("server process did not become ready in time")
+    # keep draining stdout so the child never blocks on a full pipe
+    threading.Thread(target=lambda: [None for _ in iter(proc.stdout.readline, b"")], daemon=True).start()
+    return ServerProcess(proc, info)

@@ -1,0 +1,62 @@
+"""Command line entry point of the in-repo v2 server."""
+
+from __future__ import annotations
+
+import argparse
+import json
+import signal
+import sys
+import threading
+
+from . import Server
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m triton_client_amd.server")
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--http-port", type=int, default=8000)
+    ap.add_argument("--grpc-port", type=int, default=8001)
+    ap.add_argument("--gpu", type=int, default=None, help="MI355X ordinal served by this instance (omit: CPU only)")
+    ap.add_argument("--models", default="", help="comma separated model names (default: every CPU model, plus the "
+                                                 "GPU models when --gpu is given)")
+    ap.add_argument("--model-control-mode", default="none", choices=["none", "explicit"])
+    ap.add_argument("--http-workers", type=int, default=16)
+    ap.add_argument("--grpc-workers", type=int, default=32)
+    ap.add_argument("--announce", action="store_true", help="print one JSON line with the bound ports when ready")
+    ap.add_argument("--exit-on-stdin-close", action="store_true")
+    args = ap.parse_args(argv)
+
+    from ..models import DEFAULT_CPU_MODELS, MODEL_ZOO
+
+    if args.models:
+        models = [m for m in args.models.split(",") if m]
+    else:
+        models = list(DEFAULT_CPU_MODELS)
+        if args.gpu is not None:
+            models += [n for n, c in MODEL_ZOO.items() if c.device == "gpu"]
+    server = Server(models=models, gpu=args.gpu, http_port=args.http_port, grpc_port=args.grpc_port, host=args.host,
+                    model_control=args.model_control_mode, http_workers=args.http_workers,
+                    grpc_workers=args.grpc_workers).start()
+    if args.announce:
+        print(json.dumps({"http_port": server._http_port, "grpc_port": server._grpc_port,
+                          "models": [m["name"] for m in server.core.repository_index(True)],
+                          "failed": server.core._failed}), flush=True)
+    else:
+        print(f"serving HTTP on {server.http_url}, gRPC on {server.grpc_url}", flush=True)
+    stop = threading.Event()
+    signal.signal(signal.SIGTERM, lambda *_: stop.set())
+    signal.signal(signal.SIGINT, lambda *_: stop.set())
+    if args.exit_on_stdin_close:
+        def watch():
+            try:
+                sys.stdin.buffer.read()
+            finally:
+                stop.set()
+
+        threading.Thread(target=watch, daemon=True).start()
+    stop.wait()
+    server.stop()
+
+
+if __name__ == "__main__":
+    main()

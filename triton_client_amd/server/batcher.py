@@ -1,0 +1,298 @@
+"""Dynamic batcher + asynchronous completion for GPU models.
+
+Requests submitted by transport threads are merged along the batch axis (up to
+``max_batch_size`` or ``max_queue_delay_us``) and executed as ONE forward on
+the model's HIP stream.  Enqueue and completion are decoupled: the batcher
+thread records a HIP event after enqueueing a batch and immediately starts
+forming the next one while a completer thread waits for the event and wakes
+the callers, so host-side request handling overlaps GPU execution.
+
+A batch made of a single request whose tensors live in hipshm regions runs
+zero-copy: the captured graph reads the client's input region and writes the
+client's output region directly.
+"""
+
+from __future__ import annotations
+
+import queue
+import threading
+import time
+
+import numpy as np
+
+from ..models import ModelError
+from .core import ServerError
+
+
+class _Item:
+    __slots__ = ("req", "inputs", "batch", "stable", "requested", "ctx", "stats", "t_arrive", "version", "done",
+                 "response", "error", "t_queued")
+
+    def __init__(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version):
+        self.req, self.inputs, self.batch, self.stable = req, inputs, batch, stable
+        self.requested, self.ctx, self.stats, self.t_arrive, self.version = requested, ctx, stats, t_arrive, version
+        self.done = threading.Event()
+        self.response = None
+        self.error = None
+        self.t_queued = time.perf_counter_ns()
+
+
+class DynamicBatcher:
+    def __init__(self, core, lm):
+        self.core = core
+        self.lm = lm
+        self.model = lm.model
+        self.max_batch = max(1, self.model.max_batch_size)
+        self.delay_s = float(getattr(self.model, "max_queue_delay_us", 100)) / 1e6
+        self.q = queue.Queue()
+        self.completions = queue.Queue()
+        self._held = None
+        self._stop = False
+        self._static = {}
+        self._threads = [
+            threading.Thread(target=self._batch_loop, name="tca-batcher", daemon=True),
+            threading.Thread(target=self._complete_loop, name="tca-completer", daemon=True),
+        ]
+        for t in self._threads:
+            t.start()
+
+    def stop(self):
+        self._stop = True
+        self.q.put(None)
+        self.completions.put(None)
+
+    # called on transport threads
+    def submit(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version):
+        item = _Item(req, inputs, max(1, batch), stable, requested, ctx, stats, t_arrive, version)
+        self.q.put(item)
+        item.done.wait()
+        if item.error is not None:
+            raise item.error
+        return item.response
+
+    # ------------------------------------------------------------ batching
+    def _next_group(self):
+        first = self._held or self.q.get()
+        self._held = None
+        if first is None:
+            return None
+        group, total = [first], first.batch
+        deadline = time.perf_counter() + self.delay_s
+        while total < self.max_batch:
+            try:
+                remaining = deadline - time.perf_counter()
+                nxt = self.q.get_nowait() if remaining <= 0 else self.q.get(timeout=remaining)
+            except queue.Empty:
+                break
+            if nxt is None:
+                self._stop = True
+                break
+            if total + nxt.batch > self.max_batch:
+                self._held = nxt
+                break
+            group.append(nxt)
+            total += nxt.batch
+        return group, total
+
+    def _batch_loop(self):
+        import torch
+
+        torch.cuda.set_device(self.lm.device_index or 0)
+        while not self._stop:
+            got = self._next_group()
+            if got is None:
+                break
+            group, total = got
+            try:
+                self._launch(group, total)
+            except (ServerError, ModelError) as e:
+                err = e if isinstance(e, ServerError) else ServerError(str(e), 400)
+                for it in group:
+                    it.error = err
+                    it.stats.record_fail(time.perf_counter_ns() - it.t_arrive)
+                    it.done.set()
+            except Exception as e:  # keep serving after an unexpected failure
+                err = ServerError(f"internal error while executing '{self.model.name}': {type(e).__name__}: {e}", 500)
+                for it in group:
+                    it.error = err
+                    it.done.set()
+
+    def _static_buffers(self, total, in_name, in_dtype, in_tail, out_name):
+        import torch
+
+        key = total
+        bufs = self._static.get(key)
+        if bufs is None:
+            device = torch.device("cuda", self.lm.device_index or 0)
+            bufs = (
+                torch.empty((total, *in_tail), device=device, dtype=in_dtype),
+                torch.empty((total, *self.model.outputs[0].dims), device=device, dtype=torch.float32),
+            )
+            self._static[key] = bufs
+        return bufs
+
+    def _launch(self, group, total):
+        import torch
+
+        model, core, lm = self.model, self.core, self.lm
+        out_specs = {t.name: t for t in model.outputs}
+        in_name = model.inputs[0].name
+        out_name = model.outputs[0].name
+        t_exec = time.perf_counter_ns()
+        stream = model.stream
+        pending = []  # (item, dev_inputs or None, host copies)
+        if len(group) == 1:
+            it = group[0]
+            dev_inputs = core._to_device(lm, it.inputs, it.stable)
+            for ro in it.requested:
+                dest = core._output_destination(lm, ro, out_specs[ro.name], it.batch)
+                if dest is not None:
+                    dev_inputs["__out__" + ro.name] = dest
+            x = dev_inputs[in_name]
+            if in_name not in it.stable:
+                # wire input: stage into a static buffer so the captured graph
+                # sees a stable address
+                sbuf, _ = self._static_buffers(it.batch, in_name, x.dtype, tuple(x.shape[1:]), out_name)
+                with torch.cuda.stream(stream):
+                    sbuf.copy_(x, non_blocking=True)
+                dev_inputs[in_name] = sbuf
+            if ("__out__" + out_name) not in dev_inputs:
+                _, obuf = self._static_buffers(it.batch, in_name, dev_inputs[in_name].dtype,
+                                               tuple(dev_inputs[in_name].shape[1:]), out_name)
+                dev_inputs["__out__" + out_name] = obuf
+                result = model.execute(dev_inputs, it.ctx)
+                result = self._host_copies(it, result, stream, own_static=True)
+                dev_inputs.pop("__out__" + out_name)
+            else:
+                result = model.execute(dev_inputs, it.ctx)
+            pending.append((it, dev_inputs, result))
+        else:
+            first = group[0].inputs[in_name]
+            if isinstance(first, np.ndarray):
+                in_dtype = torch.from_numpy(first[:0].copy()).dtype
+            else:
+                in_dtype = first.dtype
+            tail = tuple(first.shape[1:])
+            sbuf, obuf = self._static_buffers(total, in_name, in_dtype, tail, out_name)
+            row = 0
+            with torch.cuda.stream(stream):
+                for it in group:
+                    x = it.inputs[in_name]
+                    if isinstance(x, np.ndarray):
+                        x = torch.from_numpy(np.ascontiguousarray(x))
+                    sbuf[row: row + it.batch].copy_(x, non_blocking=True)
+                    row += it.batch
+            merged = {in_name: sbuf, "__out__" + out_name: obuf}
+            out = model.execute(merged, group[0].ctx)[out_name]
+            row = 0
+            for it in group:
+                piece = out[row: row + it.batch]
+                row += it.batch
+                dev_inputs = {}
+                placed = False
+                for ro in it.requested:
+                    dest = core._output_destination(lm, ro, out_specs[ro.name], it.batch)
+                    if dest is not None:
+                        with torch.cuda.stream(stream):
+                            dest.copy_(piece, non_blocking=True)
+                        dev_inputs["__out__" + ro.name] = dest
+                        placed = True
+                if placed:
+                    result = {out_name: dev_inputs["__out__" + out_name]}
+                else:
+                    result = self._host_copies(it, {out_name: piece}, stream, own_static=True)
+                pending.append((it, dev_inputs, result))
+        event = torch.cuda.Event()
+        event.record(stream)
+        self.completions.put((event, pending, total, t_exec, time.perf_counter_ns()))
+
+    def _host_copies(self, it, result, stream, own_static):
+        """Enqueue D2H copies (pinned) for outputs that go back over the wire,
+        so the static output buffer can be reused by the next batch."""
+        import torch
+
+        out = {}
+        needs_topk = {ro.name: ro.class_count for ro in it.requested}
+        with torch.cuda.stream(stream):
+            for name, value in result.items():
+                k = needs_topk.get(name, 0)
+                if k:
+                    vals, idx = torch.topk(value, min(k, value.shape[-1]), dim=-1)
+                    out[name] = ("topk", vals.to("cpu", non_blocking=True), idx.to("cpu", non_blocking=True))
+                else:
+                    host = torch.empty(value.shape, dtype=value.dtype, pin_memory=True)
+                    host.copy_(value, non_blocking=True)
+                    out[name] = host
+        return out
+
+    # ---------------------------------------------------------- completion
+    def _complete_loop(self):
+        import torch
+
+        torch.cuda.set_device(self.lm.device_index or 0)
+        while True:
+            entry = self.completions.get()
+            if entry is None:
+                break
+            event, pending, total, t_exec, t_enq = entry
+            event.synchronize()
+            t_done = time.perf_counter_ns()
+            out_specs = {t.name: t for t in self.model.outputs}
+            for it, dev_inputs, result in pending:
+                try:
+                    final = {}
+                    for name, value in result.items():
+                        if isinstance(value, tuple) and value[0] == "topk":
+                            final[name] = self._format_topk(value[1].numpy(), value[2].numpy(), it)
+                        elif hasattr(value, "is_cuda") and not value.is_cuda:
+                            final[name] = value.numpy()
+                        else:
+                            final[name] = value
+                    requested = it.requested
+                    # classification already applied above: strip the flag for _build_response
+                    resp = self._respond(it, final, requested, out_specs, dev_inputs)
+                    it.response = resp
+                    t_out = time.perf_counter_ns()
+                    it.stats.record(it.batch, t_exec - it.t_arrive, t_enq - t_exec, t_done - t_enq, t_out - t_done,
+                                    executions=1 if it is pending[0][0] else 0)
+                except ServerError as e:
+                    it.error = e
+                except Exception as e:
+                    it.error = ServerError(f"internal error: {type(e).__name__}: {e}", 500)
+                it.done.set()
+
+    def _format_topk(self, vals, idx, it):
+        labels = self.model.labels
+        rows, k = vals.shape
+        out = np.empty((rows, k), dtype=np.object_)
+        for r in range(rows):
+            for c in range(k):
+                i = int(idx[r, c])
+                text = "%f:%d" % (float(vals[r, c]), i)
+                if labels is not None and i < len(labels):
+                    text += ":" + labels[i]
+                out[r, c] = text.encode("utf-8")
+        return out
+
+    def _respond(self, it, final, requested, out_specs, dev_inputs):
+        from .core import InferResponse, OutputTensor
+
+        resp = InferResponse(model_name=it.req.model_name, model_version=it.version, id=it.req.id)
+        for ro in requested:
+            if ro.name not in final:
+                continue
+            value = final[ro.name]
+            spec = out_specs[ro.name]
+            key = "__out__" + ro.name
+            if dev_inputs and key in dev_inputs and value is dev_inputs[key]:
+                resp.outputs.append(OutputTensor(ro.name, spec.datatype, list(value.shape), None, ro.shm))
+                continue
+            datatype = "BYTES" if ro.class_count else spec.datatype
+            if not isinstance(value, np.ndarray):
+                value = value.detach().cpu().numpy()
+            if ro.shm is not None:
+                self.core._write_shm(ro, datatype, value)
+                resp.outputs.append(OutputTensor(ro.name, datatype, list(value.shape), None, ro.shm))
+            else:
+                resp.outputs.append(OutputTensor(ro.name, datatype, list(value.shape), value, None, ro.binary))
+        return resp

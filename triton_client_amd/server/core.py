@@ -1,0 +1,860 @@
+"""Transport independent heart of the in-repo KServe-v2 server.
+
+The reference tree has no server at all (every example needs a live Triton,
+``src/c++/tests/cc_client_test.cc:39-40``); this one exists so the client
+stack, the examples and the load generator run hermetically, and so that one
+PyTorch-ROCm model instance per MI355X can be driven through the real wire
+protocol.
+
+``InferenceCore`` owns
+
+* the model repository (zoo -> loaded instances, load/unload/index, config
+  override),
+* the shared-memory registries (system shm by key, device shm by HIP IPC
+  handle),
+* per-model statistics, trace and log settings,
+* sequence state, the dynamic batcher for GPU models and fault injection knobs
+  (``delay_ms`` / ``fail_every_n`` model parameters).
+
+The HTTP and gRPC fronts translate their wire format to :class:`InferRequest`
+and back from :class:`InferResponse`.
+"""
+
+from __future__ import annotations
+
+import base64
+import json
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from ..models import MODEL_ZOO, ExecContext, ModelError, SequenceInfo
+from ..utils import (
+    deserialize_bf16_tensor,
+    deserialize_bytes_tensor,
+    serialize_bf16_tensor,
+    serialize_byte_tensor,
+    triton_to_np_dtype,
+)
+from ..utils import shared_memory as sysshm
+
+SERVER_NAME = "triton"
+SERVER_VERSION = "2.50.0-mi355x"
+EXTENSIONS = [
+    "classification", "sequence", "model_repository", "model_repository(unload_dependents)", "schedule_policy",
+    "model_configuration", "system_shared_memory", "cuda_shared_memory", "binary_tensor_data", "parameters",
+    "statistics", "trace", "logging",
+]
+
+
+class ServerError(Exception):
+    """An error to report to the client.  ``code`` is the HTTP status; the gRPC
+    front maps 400->INVALID_ARGUMENT, 404->NOT_FOUND, 503->UNAVAILABLE, others
+    -> INTERNAL."""
+
+    def __init__(self, message, code=400):
+        super().__init__(message)
+        self.message = message
+        self.code = code
+
+
+@dataclass
+class ShmRef:
+    region: str
+    byte_size: int
+    offset: int = 0
+
+
+@dataclass
+class InputTensor:
+    name: str
+    datatype: str
+    shape: List[int]
+    data: object = None  # np.ndarray (decoded) or None when shm is set
+    raw: object = None  # undecoded wire bytes (decoded lazily against the spec)
+    json_data: object = None  # JSON "data" list
+    shm: Optional[ShmRef] = None
+
+
+@dataclass
+class RequestedOutput:
+    name: str
+    binary: Optional[bool] = None  # HTTP only; None = use request default
+    class_count: int = 0
+    shm: Optional[ShmRef] = None
+
+
+@dataclass
+class InferRequest:
+    model_name: str
+    model_version: str = ""
+    id: str = ""
+    parameters: Dict[str, object] = field(default_factory=dict)
+    inputs: List[InputTensor] = field(default_factory=list)
+    outputs: Optional[List[RequestedOutput]] = None
+    streaming: bool = False
+
+
+@dataclass
+class OutputTensor:
+    name: str
+    datatype: str
+    shape: List[int]
+    data: object = None  # np.ndarray, or None when written to shm
+    in_shm: Optional[ShmRef] = None
+    binary: Optional[bool] = None
+
+
+@dataclass
+class InferResponse:
+    model_name: str
+    model_version: str
+    id: str = ""
+    outputs: List[OutputTensor] = field(default_factory=list)
+    parameters: Dict[str, object] = field(default_factory=dict)
+
+
+# --------------------------------------------------------------------------
+# statistics
+# --------------------------------------------------------------------------
+class _Duration:
+    __slots__ = ("count", "ns")
+
+    def __init__(self):
+        self.count = 0
+        self.ns = 0
+
+    def add(self, ns, count=1):
+        self.count += count
+        self.ns += int(ns)
+
+    def as_dict(self):
+        return {"count": self.count, "ns": self.ns}
+
+
+class ModelStats:
+    FIELDS = ("success", "fail", "queue", "compute_input", "compute_infer", "compute_output", "cache_hit",
+              "cache_miss")
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.last_inference = 0
+        self.inference_count = 0
+        self.execution_count = 0
+        self.d = {k: _Duration() for k in self.FIELDS}
+        self.batch = {}
+
+    def record(self, batch, queue_ns, in_ns, infer_ns, out_ns, executions=1):
+        total = queue_ns + in_ns + infer_ns + out_ns
+        with self.lock:
+            self.last_inference = int(time.time() * 1000)
+            self.inference_count += max(1, batch)
+            self.execution_count += executions
+            self.d["success"].add(total)
+            self.d["queue"].add(queue_ns)
+            self.d["compute_input"].add(in_ns)
+            self.d["compute_infer"].add(infer_ns)
+            self.d["compute_output"].add(out_ns)
+            b = self.batch.setdefault(max(1, batch), {k: _Duration() for k in
+                                                       ("compute_input", "compute_infer", "compute_output")})
+            b["compute_input"].add(in_ns)
+            b["compute_infer"].add(infer_ns)
+            b["compute_output"].add(out_ns)
+
+    def record_fail(self, ns):
+        with self.lock:
+            self.d["fail"].add(ns)
+
+    def as_dict(self, name, version):
+        with self.lock:
+            return {
+                "name": name,
+                "version": version,
+                "last_inference": self.last_inference,
+                "inference_count": self.inference_count,
+                "execution_count": self.execution_count,
+                "inference_stats": {k: v.as_dict() for k, v in self.d.items()},
+                "batch_stats": [
+                    {"batch_size": bs, **{k: v.as_dict() for k, v in d.items()}} for bs, d in sorted(self.batch.items())
+                ],
+            }
+
+
+# --------------------------------------------------------------------------
+# shared memory registries
+# --------------------------------------------------------------------------
+class SystemShmRegistry:
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._regions = {}
+
+    def register(self, name, key, offset, byte_size):
+        with self._lock:
+            if name in self._regions:
+                raise ServerError(f"shared memory region '{name}' already in manager", 400)
+            try:
+                handle = sysshm.attach_shared_memory_region(name, key, byte_size, offset)
+            except sysshm.SharedMemoryException as e:
+                raise ServerError(f"Unable to open shared memory region: '{key}': {e}", 400) from None
+            self._regions[name] = (key, int(offset), int(byte_size), handle)
+
+    def unregister(self, name=""):
+        with self._lock:
+            names = [name] if name else list(self._regions)
+            for n in names:
+                entry = self._regions.pop(n, None)
+                if entry is not None:
+                    try:
+                        sysshm.destroy_shared_memory_region(entry[3])
+                    except sysshm.SharedMemoryException:
+                        pass
+
+    def status(self, name=""):
+        with self._lock:
+            if name:
+                if name not in self._regions:
+                    raise ServerError(f"Unable to find system shared memory region: '{name}'", 400)
+                items = {name: self._regions[name]}
+            else:
+                items = dict(self._regions)
+        return [{"name": n, "key": e[0], "offset": e[1], "byte_size": e[2]} for n, e in items.items()]
+
+    def view(self, ref: ShmRef):
+        """Writable memoryview of ``ref`` inside its region."""
+        with self._lock:
+            entry = self._regions.get(ref.region)
+        if entry is None:
+            return None
+        size = entry[2]
+        if ref.offset + ref.byte_size > size:
+            raise ServerError(
+                f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
+        return entry[3].buffer()[ref.offset: ref.offset + ref.byte_size]
+
+
+class DeviceShmRegistry:
+    """Regions opened from HIP IPC handles (protocol name: cudasharedmemory)."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._regions = {}
+
+    def register(self, name, raw_handle: bytes, device_id, byte_size):
+        from ..utils import hip_shared_memory as hipshm
+
+        with self._lock:
+            if name in self._regions:
+                raise ServerError(f"shared memory region '{name}' already in manager", 400)
+            try:
+                mapping = hipshm.open_shared_memory_region(name, raw_handle, byte_size, device_id)
+            except Exception as e:
+                raise ServerError(f"failed to register device shared memory region '{name}': {e}", 400) from None
+            self._regions[name] = (int(device_id), int(byte_size), mapping)
+
+    def unregister(self, name=""):
+        from ..utils import hip_shared_memory as hipshm
+
+        with self._lock:
+            names = [name] if name else list(self._regions)
+            for n in names:
+                entry = self._regions.pop(n, None)
+                if entry is not None:
+                    try:
+                        hipshm.close_shared_memory_region(entry[2])
+                    except Exception:
+                        pass
+
+    def status(self, name=""):
+        with self._lock:
+            if name:
+                if name not in self._regions:
+                    raise ServerError(f"Unable to find cuda shared memory region: '{name}'", 400)
+                items = {name: self._regions[name]}
+            else:
+                items = dict(self._regions)
+        return [{"name": n, "device_id": e[0], "byte_size": e[1]} for n, e in items.items()]
+
+    def get(self, name):
+        with self._lock:
+            return self._regions.get(name)
+
+
+# --------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------
+def _shape_matches(dims, shape):
+    if len(dims) != len(shape):
+        return False
+    return all(d == -1 or d == s for d, s in zip(dims, shape))
+
+
+def _decode_wire(datatype, shape, raw, name, model):
+    """Wire bytes -> ndarray of ``shape``."""
+    count = int(np.prod(shape)) if len(shape) else 1
+    if datatype == "BYTES":
+        arr = deserialize_bytes_tensor(raw)
+        if arr.size != count:
+            raise ServerError(
+                f"expected {count} string elements for inference input '{name}' for model '{model}', got {arr.size}")
+        return arr.reshape(shape)
+    if datatype == "BF16":
+        arr = deserialize_bf16_tensor(raw)
+    else:
+        npdt = triton_to_np_dtype(datatype)
+        if npdt is None:
+            raise ServerError(f"invalid datatype '{datatype}' for input '{name}'")
+        itemsize = np.dtype(npdt).itemsize
+        if len(raw) != count * itemsize:
+            raise ServerError(
+                f"unexpected total byte size {len(raw)} for input '{name}', expecting {count * itemsize}")
+        arr = np.frombuffer(raw, dtype=npdt)
+    if arr.size != count:
+        raise ServerError(f"unexpected element count {arr.size} for input '{name}', expecting {count}")
+    return arr.reshape(shape)
+
+
+def _decode_json(datatype, shape, data, name):
+    flat = np.array(data, dtype=object).reshape(-1).tolist() if isinstance(data, list) else [data]
+    count = int(np.prod(shape)) if len(shape) else 1
+    if len(flat) != count:
+        raise ServerError(f"unexpected number of elements {len(flat)} in 'data' for input '{name}', expecting {count}")
+    if datatype == "BYTES":
+        arr = np.empty(count, dtype=np.object_)
+        for i, v in enumerate(flat):
+            arr[i] = v.encode("utf-8") if isinstance(v, str) else bytes(v)
+        return arr.reshape(shape)
+    if datatype in ("FP16", "BF16"):
+        npdt = np.float16 if datatype == "FP16" else np.float32
+    else:
+        npdt = triton_to_np_dtype(datatype)
+    return np.array(flat, dtype=npdt).reshape(shape)
+
+
+def encode_wire(datatype, arr):
+    """ndarray -> wire bytes."""
+    if datatype == "BYTES":
+        packed = serialize_byte_tensor(arr)
+        return packed.item() if packed.size else b""
+    if datatype == "BF16":
+        packed = serialize_bf16_tensor(np.ascontiguousarray(arr, dtype=np.float32))
+        return packed.item() if packed.size else b""
+    return np.ascontiguousarray(arr).tobytes()
+
+
+def format_classification(values, labels, k):
+    """Top-k ``"value:index[:label]"`` strings for each row of ``values``."""
+    rows = values.reshape(-1, values.shape[-1]) if values.ndim > 1 else values.reshape(1, -1)
+    k = min(k, rows.shape[1])
+    idx = np.argsort(-rows, axis=1, kind="stable")[:, :k]
+    out = np.empty((rows.shape[0], k), dtype=np.object_)
+    for r in range(rows.shape[0]):
+        for c in range(k):
+            i = int(idx[r, c])
+            text = "%f:%d" % (float(rows[r, i]), i)
+            if labels is not None and i < len(labels):
+                text += ":" + labels[i]
+            out[r, c] = text.encode("utf-8")
+    return out if values.ndim > 1 else out.reshape(k)
+
+
+# --------------------------------------------------------------------------
+# loaded model wrapper
+# --------------------------------------------------------------------------
+class LoadedModel:
+    def __init__(self, model, device_index=None):
+        self.model = model
+        self.stats = {v: ModelStats() for v in model.versions}
+        self.sequences = {}
+        self.seq_lock = threading.Lock()
+        self.exec_lock = threading.Lock()  # CPU models run serially per instance like a single instance group
+        self.request_counter = 0
+        self.device_index = device_index
+        self.batcher = None
+
+
+class InferenceCore:
+    """See module docstring."""
+
+    def __init__(self, models=None, gpu=None, model_control="none", strict_ready=True):
+        self.gpu = gpu
+        self.model_control = model_control
+        self._lock = threading.RLock()
+        self._loaded: Dict[str, LoadedModel] = {}
+        self._failed: Dict[str, str] = {}
+        self.sysshm = SystemShmRegistry()
+        self.devshm = DeviceShmRegistry()
+        self.trace_global = {
+            "trace_file": [""], "trace_level": ["OFF"], "trace_rate": ["1000"], "trace_count": ["-1"],
+            "log_frequency": ["0"], "trace_mode": ["triton"],
+        }
+        self.trace_models: Dict[str, dict] = {}
+        self.log_settings = {
+            "log_file": "", "log_info": True, "log_warning": True, "log_error": True, "log_verbose_level": 0,
+            "log_format": "default",
+        }
+        self.live = True
+        self.ready = True
+        self._available = list(models) if models is not None else list(MODEL_ZOO)
+        if model_control != "explicit":
+            for name in self._available:
+                try:
+                    self.load_model(name)
+                except ServerError as e:
+                    self._failed[name] = e.message
+
+    # ----------------------------------------------------------- repository
+    def repository_index(self, ready_only=False):
+        out = []
+        with self._lock:
+            for name in self._available:
+                lm = self._loaded.get(name)
+                if lm is not None:
+                    for v in lm.model.versions:
+                        out.append({"name": name, "version": v, "state": "READY", "reason": ""})
+                elif not ready_only:
+                    entry = {"name": name}
+                    if name in self._failed:
+                        entry.update({"version": "1", "state": "UNAVAILABLE", "reason": self._failed[name]})
+                    out.append(entry)
+        return out
+
+    def load_model(self, name, config=None, files=None):
+        if name not in MODEL_ZOO or name not in self._available:
+            raise ServerError(f"failed to load '{name}', failed to poll from model repository", 400)
+        cls = MODEL_ZOO[name]
+        model = cls()
+        if config is not None:
+            try:
+                override = json.loads(config) if isinstance(config, (str, bytes)) else dict(config)
+            except ValueError as e:
+                raise ServerError(f"failed to load '{name}', unable to parse config override: {e}", 400) from None
+            model.apply_config_override(override)
+        elif files:
+            raise ServerError(
+                f"failed to load '{name}', override model directory requires a config override as well", 400)
+        if files:
+            model.override_files = {k: (base64.b64decode(v) if isinstance(v, str) else v) for k, v in files.items()}
+        if model.device == "gpu" and self.gpu is None:
+            raise ServerError(f"failed to load '{name}', no GPU is assigned to this server instance", 400)
+        try:
+            model.load(self.gpu if model.device == "gpu" else None)
+        except ModelError as e:
+            raise ServerError(f"failed to load '{name}': {e}", 400) from None
+        lm = LoadedModel(model, self.gpu)
+        if model.device == "gpu" and model.dynamic_batching:
+            from .batcher import DynamicBatcher
+
+            lm.batcher = DynamicBatcher(self, lm)
+        with self._lock:
+            old = self._loaded.get(name)
+            self._loaded[name] = lm
+            self._failed.pop(name, None)
+        if old is not None:
+            self._retire(old)
+
+    def _retire(self, lm):
+        if lm.batcher is not None:
+            lm.batcher.stop()
+        try:
+            lm.model.unload()
+        except Exception:
+            pass
+
+    def unload_model(self, name, unload_dependents=False):
+        with self._lock:
+            lm = self._loaded.pop(name, None)
+        if lm is None and name not in self._available:
+            raise ServerError(f"failed to unload '{name}', model is not found", 400)
+        if lm is not None:
+            self._retire(lm)
+
+    def _get(self, name, version="") -> LoadedModel:
+        with self._lock:
+            lm = self._loaded.get(name)
+        if lm is None:
+            raise ServerError(f"Request for unknown model: '{name}' is not found", 400)
+        if version and version not in lm.model.versions:
+            raise ServerError(f"Request for unknown model: '{name}' version {version} is not found", 400)
+        return lm
+
+    def is_model_ready(self, name, version=""):
+        try:
+            self._get(name, version)
+            return True
+        except ServerError:
+            return False
+
+    def server_metadata(self):
+        return {"name": SERVER_NAME, "version": SERVER_VERSION, "extensions": list(EXTENSIONS)}
+
+    def model_metadata(self, name, version=""):
+        lm = self._get(name, version)
+        md = lm.model.metadata()
+        if version:
+            md["versions"] = [version]
+        return md
+
+    def model_config(self, name, version=""):
+        return self._get(name, version).model.config()
+
+    def statistics(self, name="", version=""):
+        out = []
+        with self._lock:
+            items = list(self._loaded.items())
+        if name:
+            lm = self._get(name, version)
+            items = [(name, lm)]
+        for n, lm in items:
+            for v, st in lm.stats.items():
+                if version and v != version:
+                    continue
+                out.append(st.as_dict(n, v))
+        return {"model_stats": out}
+
+    # ----------------------------------------------------------- trace / log
+    def update_trace(self, model_name, settings):
+        if model_name:
+            self._get(model_name)
+            target = self.trace_models.setdefault(model_name, {})
+        else:
+            target = self.trace_global
+        for key, value in (settings or {}).items():
+            if key not in self.trace_global:
+                raise ServerError(f"unsupported trace setting '{key}'", 400)
+            if value is None or value == []:
+                if model_name:
+                    target.pop(key, None)  # fall back to the global value
+                continue
+            values = value if isinstance(value, list) else [value]
+            target[key] = [str(v) for v in values]
+        return self.get_trace(model_name)
+
+    def get_trace(self, model_name=None):
+        merged = {k: list(v) for k, v in self.trace_global.items()}
+        if model_name:
+            self._get(model_name)
+            for k, v in self.trace_models.get(model_name, {}).items():
+                merged[k] = list(v)
+        return merged
+
+    def update_log(self, settings):
+        for key, value in (settings or {}).items():
+            if key not in self.log_settings:
+                raise ServerError(f"unsupported log setting '{key}'", 400)
+            if value is None:
+                continue
+            self.log_settings[key] = value
+        return dict(self.log_settings)
+
+    # -------------------------------------------------------------- infer
+    def _prepare_inputs(self, lm: LoadedModel, req: InferRequest):
+        """Validate against the model signature and materialise the inputs.
+
+        Returns ``(inputs: dict, batch: int, device_views: set)``."""
+        model = lm.model
+        specs = {t.name: t for t in model.inputs}
+        seen = set()
+        inputs = {}
+        batch = 0
+        gpu = model.device == "gpu"
+        stable = set()
+        for t in req.inputs:
+            spec = specs.get(t.name)
+            if spec is None:
+                raise ServerError(f"unexpected inference input '{t.name}' for model '{model.name}'")
+            if t.name in seen:
+                raise ServerError(f"input '{t.name}' already exists in request")
+            seen.add(t.name)
+            if t.datatype != spec.datatype:
+                raise ServerError(
+                    f"inference input '{t.name}' data-type is '{t.datatype}', but model '{model.name}' expects "
+                    f"'{spec.datatype}'")
+            shape = [int(s) for s in t.shape]
+            dims = list(spec.dims)
+            if model.max_batch_size > 0:
+                if len(shape) < 1 or not _shape_matches(dims, shape[1:]):
+                    raise ServerError(
+                        f"unexpected shape for input '{t.name}' for model '{model.name}'. Expected "
+                        f"{[-1] + dims}, got {shape}")
+                if shape[0] > model.max_batch_size:
+                    raise ServerError(
+                        f"inference request batch-size must be <= {model.max_batch_size} for '{model.name}'")
+                batch = max(batch, shape[0])
+            elif not _shape_matches(dims, shape):
+                raise ServerError(
+                    f"unexpected shape for input '{t.name}' for model '{model.name}'. Expected {dims}, got {shape}")
+            if t.shm is not None:
+                arr = self._read_shm(t, shape, model, gpu)
+                if gpu and not isinstance(arr, np.ndarray):
+                    stable.add(t.name)
+            elif t.data is not None:
+                arr = t.data
+            elif t.raw is not None:
+                arr = _decode_wire(t.datatype, shape, t.raw, t.name, model.name)
+            elif t.json_data is not None:
+                arr = _decode_json(t.datatype, shape, t.json_data, t.name)
+            else:
+                raise ServerError(f"input '{t.name}' for model '{model.name}' has no data")
+            inputs[t.name] = arr
+        missing = [n for n, s in specs.items() if n not in seen and not s.optional]
+        if missing:
+            raise ServerError(
+                f"expected {len(specs)} inputs but got {len(seen)} inputs for model '{model.name}'. "
+                f"Got input(s) {sorted(seen)}, but missing required input(s) {missing}. "
+                "Please provide all required input(s).")
+        return inputs, batch, stable
+
+    def _read_shm(self, t: InputTensor, shape, model, gpu):
+        ref = t.shm
+        view = self.sysshm.view(ref)
+        if view is not None:
+            return _decode_wire(t.datatype, shape, view, t.name, model.name)
+        entry = self.devshm.get(ref.region)
+        if entry is None:
+            raise ServerError(f"Unable to find shared memory region: '{ref.region}'", 400)
+        from ..utils import hip_shared_memory as hipshm
+
+        device_id, size, mapping = entry
+        if ref.offset + ref.byte_size > size:
+            raise ServerError(f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
+        if gpu and t.datatype != "BYTES":
+            return hipshm.mapping_as_torch(mapping, t.datatype, shape, ref.offset)
+        host = hipshm.read_mapping(mapping, ref.offset, ref.byte_size)
+        return _decode_wire(t.datatype, shape, host, t.name, model.name)
+
+    def _output_destination(self, lm, ro: RequestedOutput, spec, batch):
+        """For GPU models: a torch view of the device shm destination, if any."""
+        if ro.shm is None or ro.class_count:
+            return None
+        entry = self.devshm.get(ro.shm.region)
+        if entry is None or spec.datatype == "BYTES" or any(d < 0 for d in spec.dims):
+            return None
+        from ..utils import hip_shared_memory as hipshm
+
+        shape = ([batch] if lm.model.max_batch_size > 0 else []) + list(spec.dims)
+        need = int(np.prod(shape)) * np.dtype(triton_to_np_dtype(spec.datatype)).itemsize
+        if need > ro.shm.byte_size or ro.shm.offset + need > entry[1]:
+            raise ServerError(
+                f"shared memory size specified with the request for output '{ro.name}' ({ro.shm.byte_size} bytes) "
+                f"should be at least {need} bytes to hold the results")
+        return hipshm.mapping_as_torch(entry[2], spec.datatype, shape, ro.shm.offset)
+
+    def _sequence_ctx(self, lm, req):
+        params = req.parameters
+        seq_id = params.get("sequence_id", 0)
+        if not lm.model.sequence:
+            return None
+        if seq_id in (0, "", None):
+            raise ServerError(
+                f"inference request to model '{lm.model.name}' must specify a non-zero or non-empty correlation ID")
+        start = bool(params.get("sequence_start", False))
+        end = bool(params.get("sequence_end", False))
+        with lm.seq_lock:
+            state = lm.sequences.get(seq_id)
+            if start or state is None:
+                if state is None and not start:
+                    raise ServerError(
+                        f"inference request for sequence {seq_id} to model '{lm.model.name}' must specify the START "
+                        "flag on the first request of the sequence")
+                state = {}
+                lm.sequences[seq_id] = state
+            if end:
+                lm.sequences.pop(seq_id, None)
+        return SequenceInfo(sequence_id=seq_id, start=start, end=end, state=state)
+
+    def _inject_faults(self, lm, req):
+        params = lm.model.parameters
+        delay = params.get("delay_ms")
+        if delay:
+            time.sleep(float(delay) / 1000.0)
+        every = params.get("fail_every_n")
+        if every:
+            lm.request_counter += 1
+            if lm.request_counter % int(every) == 0:
+                raise ServerError(f"injected failure for model '{lm.model.name}' (fail_every_n={every})", 500)
+
+    def infer(self, req: InferRequest):
+        """Run one request.  Returns an :class:`InferResponse` for ordinary
+        models, or an iterator of them for decoupled models."""
+        t_arrive = time.perf_counter_ns()
+        lm = self._get(req.model_name, req.model_version)
+        model = lm.model
+        version = req.model_version or model.versions[-1]
+        stats = lm.stats[version]
+        try:
+            if model.decoupled and not req.streaming:
+                raise ServerError(
+                    f"doesn't support models with decoupled transaction policy: model '{model.name}' must be called "
+                    "through the streaming API", 400)
+            self._inject_faults(lm, req)
+            t0 = time.perf_counter_ns()
+            inputs, batch, stable = self._prepare_inputs(lm, req)
+            out_specs = {t.name: t for t in model.outputs}
+            requested = req.outputs
+            if requested:
+                for ro in requested:
+                    if ro.name not in out_specs:
+                        raise ServerError(f"unexpected inference output '{ro.name}' for model '{model.name}'")
+            else:
+                requested = [RequestedOutput(name=t.name) for t in model.outputs]
+            ctx = ExecContext(request_id=req.id, parameters=req.parameters, version=version,
+                              requested_outputs=[r.name for r in requested])
+            ctx.sequence = self._sequence_ctx(lm, req)
+            ctx.stable_inputs = stable
+            if model.device == "gpu":
+                if lm.batcher is not None:
+                    return lm.batcher.submit(req, inputs, batch, stable, requested, ctx, stats, t_arrive, version)
+                return self._run_gpu_single(lm, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version)
+            t1 = time.perf_counter_ns()
+            with lm.exec_lock:
+                t_exec = time.perf_counter_ns()
+                result = model.execute(inputs, ctx)
+                t2 = time.perf_counter_ns()
+            if model.decoupled:
+                return self._decoupled_iter(lm, req, result, requested, out_specs, version, stats, t_arrive)
+            response = self._build_response(lm, req, result, requested, out_specs, version, batch)
+            t3 = time.perf_counter_ns()
+            stats.record(batch, (t0 - t_arrive) + (t_exec - t1), t1 - t0, t2 - t_exec, t3 - t2)
+            return response
+        except ModelError as e:
+            stats.record_fail(time.perf_counter_ns() - t_arrive)
+            raise ServerError(str(e), 400) from None
+        except ServerError:
+            stats.record_fail(time.perf_counter_ns() - t_arrive)
+            raise
+
+    # -- GPU helpers (torch imported lazily: CPU-only servers never need it) --
+    def _to_device(self, lm, inputs, stable):
+        import torch
+
+        device = torch.device("cuda", lm.device_index or 0)
+        out = {}
+        for name, arr in inputs.items():
+            if isinstance(arr, np.ndarray):
+                if arr.dtype == np.object_:
+                    out[name] = arr
+                    continue
+                host = torch.from_numpy(np.ascontiguousarray(arr))
+                out[name] = host.to(device, non_blocking=True)
+            else:
+                out[name] = arr
+        return out
+
+    def _run_gpu_single(self, lm, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version):
+        model = lm.model
+        out_specs = {t.name: t for t in model.outputs}
+        t0 = time.perf_counter_ns()
+        with lm.exec_lock:
+            t_exec = time.perf_counter_ns()
+            dev_inputs = self._to_device(lm, inputs, stable)
+            for ro in requested:
+                dest = self._output_destination(lm, ro, out_specs[ro.name], batch)
+                if dest is not None:
+                    dev_inputs["__out__" + ro.name] = dest
+            t1 = time.perf_counter_ns()
+            result = model.execute(dev_inputs, ctx)
+            model.stream.synchronize()
+            t2 = time.perf_counter_ns()
+        response = self._build_response(lm, req, result, requested, out_specs, version, batch, dev_inputs)
+        t3 = time.perf_counter_ns()
+        stats.record(batch, (t_exec - t_arrive), t1 - t_exec, t2 - t1, t3 - t2)
+        return response
+
+    def _decoupled_iter(self, lm, req, generator, requested, out_specs, version, stats, t_arrive):
+        want_final = bool(req.parameters.get("triton_enable_empty_final_response", False))
+
+        def gen():
+            count = 0
+            try:
+                for result in generator:
+                    resp = self._build_response(lm, req, result, requested, out_specs, version, 0)
+                    if want_final:
+                        resp.parameters["triton_final_response"] = False
+                    count += 1
+                    yield resp
+                if want_final:
+                    yield InferResponse(model_name=req.model_name, model_version=version, id=req.id,
+                                        parameters={"triton_final_response": True})
+                stats.record(1, 0, 0, time.perf_counter_ns() - t_arrive, 0)
+            except ModelError as e:
+                stats.record_fail(time.perf_counter_ns() - t_arrive)
+                raise ServerError(str(e), 400) from None
+
+        return gen()
+
+    def _build_response(self, lm, req, result, requested, out_specs, version, batch, dev_inputs=None):
+        model = lm.model
+        response = InferResponse(model_name=req.model_name, model_version=version, id=req.id)
+        for ro in requested:
+            spec = out_specs[ro.name]
+            if ro.name not in result:
+                continue
+            value = result[ro.name]
+            preplaced = dev_inputs is not None and ("__out__" + ro.name) in dev_inputs and \
+                value is dev_inputs["__out__" + ro.name]
+            if preplaced:
+                response.outputs.append(OutputTensor(ro.name, spec.datatype, list(value.shape), None, ro.shm))
+                continue
+            datatype = spec.datatype
+            if ro.class_count:
+                value = self._classify(lm, value, ro.class_count)
+                datatype = "BYTES"
+            elif not isinstance(value, np.ndarray):
+                value = self._to_host(value)
+            if datatype not in ("BYTES", "BF16"):
+                want = triton_to_np_dtype(datatype)
+                if value.dtype != want:
+                    value = value.astype(want)
+            shape = list(value.shape)
+            if ro.shm is not None:
+                self._write_shm(ro, datatype, value)
+                response.outputs.append(OutputTensor(ro.name, datatype, shape, None, ro.shm))
+            else:
+                response.outputs.append(OutputTensor(ro.name, datatype, shape, value, None, ro.binary))
+        return response
+
+    def _to_host(self, value):
+        return value.detach().cpu().numpy()
+
+    def _classify(self, lm, value, k):
+        labels = lm.model.labels
+        if not isinstance(value, np.ndarray):
+            from ..ops import classification
+
+            return classification.topk_strings(value, k, labels)
+        return format_classification(value, labels, k)
+
+    def _write_shm(self, ro: RequestedOutput, datatype, value):
+        ref = ro.shm
+        blob = encode_wire(datatype, value)
+        if len(blob) > ref.byte_size:
+            raise ServerError(
+                f"shared memory size specified with the request for output '{ro.name}' ({ref.byte_size} bytes) "
+                f"should be at least {len(blob)} bytes to hold the results")
+        view = self.sysshm.view(ShmRef(ref.region, len(blob), ref.offset))
+        if view is not None:
+            view[:] = blob
+            return
+        entry = self.devshm.get(ref.region)
+        if entry is None:
+            raise ServerError(f"Unable to find shared memory region: '{ref.region}'", 400)
+        from ..utils import hip_shared_memory as hipshm
+
+        if ref.offset + len(blob) > entry[1]:
+            raise ServerError(f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
+        hipshm.write_mapping(entry[2], ref.offset, blob)
+
+    def shutdown(self):
+        with self._lock:
+            loaded = list(self._loaded.values())
+            self._loaded.clear()
+        for lm in loaded:
+            self._retire(lm)
+        self.sysshm.unregister()
+        try:
+            self.devshm.unregister()
+        except Exception:
+            pass

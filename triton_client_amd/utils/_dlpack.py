@@ -168,6 +168,12 @@ def _capsule_destructor(capsule_ptr):
         _release_managed(address)
 
 
+try:  # native producer: its deleter is safe to run during interpreter shutdown
+    from .._lib import _tca_pyext as _ext  # type: ignore
+except Exception:  # pragma: no cover
+    _ext = None
+
+
 def make_capsule(address, dl_dtype, shape, device_type, device_id, owner=None):
     """Wrap raw memory as a non-owning ``"dltensor"`` PyCapsule.
 
@@ -175,6 +181,10 @@ def make_capsule(address, dl_dtype, shape, device_type, device_id, owner=None):
     DLPack deleter, which is how a shared-memory region outlives the tensors
     that alias it.
     """
+    if _ext is not None and hasattr(_ext, "make_dlpack_capsule"):
+        return _ext.make_dlpack_capsule(int(address), int(dl_dtype.type_code), int(dl_dtype.bits),
+                                        int(dl_dtype.lanes), [int(s) for s in shape], int(device_type),
+                                        int(device_id), owner)
     ndim = len(shape)
     shape_arr = (ctypes.c_int64 * max(ndim, 1))(*shape)
     managed = DLManagedTensor()

@@ -1,0 +1,334 @@
+"""hipshm – device shared-memory regions on HIP IPC for MI355X.
+
+Drop-in for ``tritonclient.utils.cuda_shared_memory`` (reference
+``utils/cuda_shared_memory/__init__.py:107-429``): same function names and
+semantics, but implemented natively (``csrc/hip/hipshm.cc``) on
+``hipMalloc`` / ``hipIpcGetMemHandle`` / ``hipIpcOpenMemHandle`` with pinned
+double-buffered staging.  ``import tritonclient.utils.cuda_shared_memory``
+resolves to this module.
+
+Client side
+    ``create_shared_memory_region``, ``get_raw_handle``,
+    ``set_shared_memory_region`` (numpy), ``set_shared_memory_region_from_dlpack``
+    (torch-ROCm / numpy / any DLPack exporter), ``get_contents_as_numpy``
+    (copies only the requested range), ``as_shared_memory_tensor`` (zero-copy
+    ``kDLROCM`` view), ``allocated_shared_memory_regions``,
+    ``destroy_shared_memory_region``.
+Server side
+    ``open_shared_memory_region`` / ``close_shared_memory_region`` (the opening
+    process must differ from the exporting one – a HIP IPC rule),
+    ``mapping_as_torch``, ``read_mapping``, ``write_mapping``.
+
+Setting ``TCA_HIPSHM_FAKE=1`` switches to host-backed regions with the same
+API for machines without a GPU (protocol tests); it is never chosen silently.
+"""
+
+from __future__ import annotations
+
+import base64
+import ctypes
+from ctypes import byref, c_int, c_uint8, c_uint64, c_void_p
+
+import numpy as np
+
+from ... import _native
+from .. import _dlpack, triton_to_np_dtype
+from .._shared_memory_tensor import SharedMemoryTensor
+
+__all__ = [
+    "HipSharedMemoryException",
+    "CudaSharedMemoryException",
+    "HipSharedMemoryRegion",
+    "CudaSharedMemoryRegion",
+    "create_shared_memory_region",
+    "get_raw_handle",
+    "set_shared_memory_region",
+    "get_contents_as_numpy",
+    "set_shared_memory_region_from_dlpack",
+    "as_shared_memory_tensor",
+    "allocated_shared_memory_regions",
+    "destroy_shared_memory_region",
+    "open_shared_memory_region",
+    "close_shared_memory_region",
+    "mapping_as_torch",
+    "read_mapping",
+    "write_mapping",
+    "device_memory_info",
+]
+
+
+class HipSharedMemoryException(Exception):
+    """Failure of a device shared-memory operation."""
+
+    def __init__(self, msg):
+        self._msg = msg
+        super().__init__(msg)
+
+    def __str__(self):
+        return self._msg
+
+
+# name used by code written against the reference module
+CudaSharedMemoryException = HipSharedMemoryException
+
+
+def _lib():
+    return _native.hip()
+
+
+def _check(rc, what):
+    if rc != 0:
+        detail = _lib().tca_hip_last_error().decode("utf-8", "replace")
+        raise HipSharedMemoryException(f"{what}: {detail}" if detail else what)
+
+
+class HipSharedMemoryRegion:
+    """Handle of a region (owned allocation or opened IPC mapping)."""
+
+    def __init__(self, native, opened=False):
+        self._h = native
+        self._opened = opened
+        ptr, dev, size, host = c_void_p(), c_int(), c_uint64(), c_int()
+        raw = (c_uint8 * 64)()
+        _check(_lib().tca_hipshm_info(native, byref(ptr), raw, byref(dev), byref(size), byref(host)),
+               "unable to query device shared memory region")
+        self._base_addr = ptr.value or 0
+        self._raw = bytes(raw)
+        self._device_id = dev.value
+        self._byte_size = size.value
+        self._host_backed = bool(host.value)
+
+    @property
+    def byte_size(self):
+        return self._byte_size
+
+    @property
+    def device_id(self):
+        return self._device_id
+
+    @property
+    def address(self):
+        return self._base_addr
+
+    @property
+    def host_backed(self):
+        return self._host_backed
+
+    def _native(self):
+        if self._h is None:
+            raise HipSharedMemoryException("device shared memory region has been destroyed")
+        return self._h
+
+    def _dlpack_device_id(self):
+        return -1 if self._host_backed else self._device_id
+
+    def __repr__(self):
+        return (f"HipSharedMemoryRegion(device={self._device_id}, byte_size={self._byte_size}, "
+                f"host_backed={self._host_backed})")
+
+
+CudaSharedMemoryRegion = HipSharedMemoryRegion
+
+_allocated = []
+
+
+def device_memory_info(device_id=0):
+    """``(free_bytes, total_bytes)`` of a GPU (288 GB HBM3E on MI355X)."""
+    free, total = c_uint64(), c_uint64()
+    _check(_lib().tca_hip_mem_info(int(device_id), byref(free), byref(total)), "unable to query device memory")
+    return free.value, total.value
+
+
+def create_shared_memory_region(triton_shm_name, byte_size, device_id):
+    """Allocate ``byte_size`` bytes on GPU ``device_id`` and export an IPC handle."""
+    h = c_void_p()
+    name = triton_shm_name.encode("utf-8") if isinstance(triton_shm_name, str) else bytes(triton_shm_name)
+    rc = _lib().tca_hipshm_create(name, int(byte_size), int(device_id), byref(h))
+    _check(rc, "unable to create device shared memory handle")
+    region = HipSharedMemoryRegion(h)
+    region._name = triton_shm_name
+    _allocated.append(region)
+    return region
+
+
+def get_raw_handle(shm_handle):
+    """Base64 of the 64-byte HIP IPC handle (what ``register_cuda_shared_memory`` takes)."""
+    return base64.b64encode(shm_handle._raw)
+
+
+def _as_buffer(value):
+    """``(address, nbytes, keepalive)`` of a numpy array / serialized BYTES carrier."""
+    if value.dtype == np.object_:
+        blob = value.item() if value.size else b""
+        if not isinstance(blob, (bytes, bytearray)):
+            raise HipSharedMemoryException(
+                "object arrays must be serialized with serialize_byte_tensor before being placed in shared memory")
+        buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob) if len(blob) else None
+        return (ctypes.addressof(buf) if buf is not None else 0), len(blob), buf
+    arr = np.ascontiguousarray(value)
+    return arr.ctypes.data, arr.nbytes, arr
+
+
+def set_shared_memory_region(shm_handle, input_values, offset=0):
+    """Copy numpy arrays back-to-back into the region (host -> device)."""
+    if not isinstance(input_values, (list, tuple)):
+        raise HipSharedMemoryException("input_values must be specified as a list/tuple of numpy arrays")
+    for value in input_values:
+        if not isinstance(value, np.ndarray):
+            raise HipSharedMemoryException("input_values must be specified as a list/tuple of numpy arrays")
+    cursor = int(offset)
+    for value in input_values:
+        addr, nbytes, keep = _as_buffer(value)
+        _check(_lib().tca_hipshm_write(shm_handle._native(), cursor, addr, nbytes),
+               "unable to set values in device shared memory")
+        cursor += nbytes
+        del keep
+
+
+def _read(shm_handle, offset, nbytes):
+    out = np.empty(nbytes, dtype=np.uint8)
+    _check(_lib().tca_hipshm_read(shm_handle._native(), int(offset), out.ctypes.data, int(nbytes)),
+           "failed to read device shared memory results")
+    return out
+
+
+def get_contents_as_numpy(shm_handle, datatype, shape, offset=0):
+    """Device -> host copy of just the bytes the requested tensor occupies."""
+    dt = np.dtype(datatype)
+    count = int(np.prod(shape)) if len(shape) else 1
+    if dt != np.object_ and dt.type != np.bytes_:
+        need = count * dt.itemsize
+        if offset + need > shm_handle.byte_size:
+            raise HipSharedMemoryException(
+                "The size of the shared memory region is insufficient to provide numpy array with requested size")
+        if need == 0:
+            return np.empty(shape, dtype=dt)
+        return _read(shm_handle, offset, need).view(dt).reshape(shape)
+    # BYTES: element sizes are unknown up front -> fetch the tail of the region
+    # once and parse `count` elements out of it
+    from .. import shared_memory as _sys  # noqa: F401  (keeps error codes in one place)
+    from .. import _fast
+
+    blob = _read(shm_handle, offset, shm_handle.byte_size - offset)
+    try:
+        if _fast is not None:
+            items = _fast.unpack_bytes(blob.data, count)
+        else:
+            import struct
+
+            items, pos = [], 0
+            raw = blob.tobytes()
+            for _ in range(count):
+                (n,) = struct.unpack_from("<I", raw, pos)
+                pos += 4
+                if pos + n > len(raw):
+                    raise ValueError
+                items.append(raw[pos: pos + n])
+                pos += n
+    except Exception:
+        raise HipSharedMemoryException("malformed BYTES tensor in device shared memory region") from None
+    out = np.empty(count, dtype=np.object_)
+    for i, item in enumerate(items):
+        out[i] = item
+    return out.reshape(shape)
+
+
+_DEVICE_TYPES = (_dlpack.DLDeviceType.kDLROCM, _dlpack.DLDeviceType.kDLCUDA)
+_HOST_TYPES = (_dlpack.DLDeviceType.kDLCPU, _dlpack.DLDeviceType.kDLROCMHost, _dlpack.DLDeviceType.kDLCUDAHost)
+
+
+def set_shared_memory_region_from_dlpack(shm_handle, input_values, offset=0):
+    """Copy DLPack tensors (torch-ROCm on any GPU, numpy, ...) into the region.
+
+    Device sources are copied device-to-device (over xGMI when the source sits
+    on a peer GPU); host sources go through the pinned staging ring.
+    """
+    cursor = int(offset)
+    for value in input_values:
+        device = _dlpack.get_dlpack_device(value)
+        if device is not None and device[0] not in _DEVICE_TYPES + _HOST_TYPES:
+            raise HipSharedMemoryException("DLPack device type {} is not supported".format(device[0]))
+        # order the producer's work before our copy: torch hands out the capsule
+        # after synchronising its current stream with the legacy default stream
+        if device is not None and device[0] in _DEVICE_TYPES:
+            try:
+                capsule = value.__dlpack__(stream=0)
+            except TypeError:
+                capsule = value.__dlpack__()
+        else:
+            capsule = _dlpack.get_dlpack_capsule(value)
+        managed = _dlpack.get_managed_tensor(capsule)
+        t = managed.dl_tensor
+        if not _dlpack.is_contiguous_data(t.ndim, t.shape, t.strides):
+            raise HipSharedMemoryException(
+                "DLPack tensor is not contiguous. Only contiguous DLPack tensors that are stored in C-Order are "
+                "supported.")
+        nbytes = _dlpack.get_byte_size(t.dtype, t.ndim, t.shape)
+        src = (t.data or 0) + t.byte_offset
+        src_device = t.device.device_id if t.device.device_type in _DEVICE_TYPES else -1
+        if src_device >= 0 and shm_handle.host_backed:
+            raise HipSharedMemoryException("host-backed (fake) regions cannot ingest device tensors")
+        _check(_lib().tca_hipshm_copy_from(shm_handle._native(), cursor, src, nbytes, src_device),
+               "unable to set values in device shared memory")
+        cursor += nbytes
+        del capsule
+
+
+def as_shared_memory_tensor(shm_handle, datatype, shape, offset=0):
+    """Zero-copy DLPack view (``kDLROCM``) of the region, e.g. for ``torch.from_dlpack``."""
+    return SharedMemoryTensor(datatype, shape, shm_handle._base_addr, offset, shm_handle._byte_size - offset,
+                              shm_handle._dlpack_device_id(), owner=shm_handle)
+
+
+def allocated_shared_memory_regions():
+    """Regions created by this process and not yet destroyed."""
+    return _allocated
+
+
+def destroy_shared_memory_region(shm_handle):
+    """Free the device memory (unregister it from the server first)."""
+    try:
+        _allocated.remove(shm_handle)
+    except ValueError:
+        pass
+    h, shm_handle._h = shm_handle._h, None
+    if h is not None:
+        _check(_lib().tca_hipshm_destroy(h), "unable to free device shared memory")
+
+
+# ---------------------------------------------------------------- server side
+def open_shared_memory_region(name, raw_handle, byte_size, device_id):
+    """Map a region exported by another process from its 64 raw handle bytes."""
+    if len(raw_handle) != 64:
+        raise HipSharedMemoryException(f"a HIP IPC handle is 64 bytes, got {len(raw_handle)}")
+    h = c_void_p()
+    rc = _lib().tca_hipshm_open(name.encode("utf-8"), bytes(raw_handle), int(byte_size), int(device_id), byref(h))
+    _check(rc, "unable to open device shared memory handle")
+    return HipSharedMemoryRegion(h, opened=True)
+
+
+def close_shared_memory_region(mapping):
+    h, mapping._h = mapping._h, None
+    if h is not None:
+        _check(_lib().tca_hipshm_destroy(h), "unable to close device shared memory mapping")
+
+
+def mapping_as_torch(mapping, datatype, shape, offset=0):
+    """``torch`` tensor aliasing the mapping (device tensor, or CPU tensor for
+    host-backed regions)."""
+    import torch
+
+    smt = SharedMemoryTensor(datatype, shape, mapping._base_addr, offset, mapping._byte_size - offset,
+                             mapping._dlpack_device_id(), owner=mapping)
+    return torch.from_dlpack(smt)
+
+
+def read_mapping(mapping, offset, nbytes):
+    """Bytes ``[offset, offset+nbytes)`` of the mapping as a host buffer."""
+    return _read(mapping, offset, nbytes).data
+
+
+def write_mapping(mapping, offset, blob):
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    _check(_lib().tca_hipshm_write(mapping._native(), int(offset), buf.ctypes.data, buf.nbytes),
+           "unable to write device shared memory")
