@@ -1,0 +1,207 @@
+"""hipshm on a real MI355X (intent of the reference's
+``src/python/library/tests/test_cuda_shared_memory.py:37-164``) plus the
+cross-process IPC path through the in-repo server."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hipshm():
+    import tritonclient.utils.cuda_shared_memory as mod
+
+    assert not mod._lib().tca_hipshm_fake_mode(), "GPU tests must run against real device memory"
+    return mod
+
+
+def test_dlpack_from_gpu(hipshm):
+    import torch
+
+    gpu_tensor = torch.ones(4, 4).cuda(0)
+    h = hipshm.create_shared_memory_region("hipshm_data", 64, 0)
+    hipshm.set_shared_memory_region_from_dlpack(h, [gpu_tensor])
+    smt = hipshm.as_shared_memory_tensor(h, "FP32", [4, 4])
+    t = torch.from_dlpack(smt)
+    assert t.is_cuda and torch.allclose(gpu_tensor, t)
+    # zero copy: writing through the view is visible in the region
+    t.fill_(3.0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(hipshm.get_contents_as_numpy(h, np.float32, [4, 4]), np.full((4, 4), 3.0, np.float32))
+    del t, smt
+    hipshm.destroy_shared_memory_region(h)
+
+
+def test_dlpack_from_cpu_and_numpy(hipshm):
+    import torch
+
+    cpu = np.arange(16, dtype=np.float32).reshape(4, 4)
+    h = hipshm.create_shared_memory_region("hipshm_data", 64, 0)
+    hipshm.set_shared_memory_region_from_dlpack(h, [cpu])
+    t = torch.from_dlpack(hipshm.as_shared_memory_tensor(h, "FP32", [4, 4]))
+    np.testing.assert_array_equal(t.cpu().numpy(), cpu)
+    hipshm.set_shared_memory_region(h, [cpu * 2])
+    np.testing.assert_array_equal(hipshm.get_contents_as_numpy(h, np.float32, [4, 4]), cpu * 2)
+    # partial range read
+    np.testing.assert_array_equal(hipshm.get_contents_as_numpy(h, np.float32, [2, 4], offset=32), (cpu * 2)[2:])
+    with pytest.raises(hipshm.CudaSharedMemoryException):
+        hipshm.get_contents_as_numpy(h, np.float32, [4, 5])
+    del t
+    hipshm.destroy_shared_memory_region(h)
+    assert h not in hipshm.allocated_shared_memory_regions()
+
+
+def test_numpy_bytes(hipshm):
+    import tritonclient.utils as utils
+
+    ints = np.arange(16, dtype=np.int32)
+    strs = np.array([str(x).encode("utf-8") for x in ints], dtype=object)
+    packed = utils.serialize_byte_tensor(strs)
+    size = utils.serialized_byte_size(packed)
+    h = hipshm.create_shared_memory_region("hipshm_data", size, 0)
+    hipshm.set_shared_memory_region(h, [packed])
+    got = hipshm.get_contents_as_numpy(h, np.object_, [16])
+    assert np.array_equal(strs, got)
+    hipshm.destroy_shared_memory_region(h)
+
+
+def test_large_region_staged_copies(hipshm):
+    n = (40 << 20) // 4 + 3  # > 2 staging chunks, not chunk aligned
+    data = np.random.default_rng(0).integers(0, 1 << 30, size=n, dtype=np.int32)
+    h = hipshm.create_shared_memory_region("big", data.nbytes, 0)
+    hipshm.set_shared_memory_region(h, [data])
+    back = hipshm.get_contents_as_numpy(h, np.int32, [n])
+    assert np.array_equal(back, data)
+    free, total = hipshm.device_memory_info(0)
+    assert total > 200 * (1 << 30)  # MI355X: 288 GB HBM3E
+    with pytest.raises(hipshm.CudaSharedMemoryException, match="does not fit"):
+        hipshm.create_shared_memory_region("too_big", total * 2, 0)
+    hipshm.destroy_shared_memory_region(h)
+
+
+@pytest.fixture(scope="module")
+def gpu_server():
+    from triton_client_amd.server import spawn_server
+
+    srv = spawn_server(models=["simple", "simple_string", "resnet50"], gpu=0)
+    yield srv
+    srv.stop()
+
+
+@pytest.mark.parametrize("proto", ["http", "grpc"])
+def test_simple_over_hipshm_ipc(hipshm, gpu_server, proto):
+    """simple_{http,grpc}_cudashm_client intent: the server process opens the
+    IPC handle and reads/writes GPU memory the client allocated."""
+    if proto == "http":
+        import tritonclient.http as mod
+
+        c = mod.InferenceServerClient(gpu_server.http_url)
+    else:
+        import tritonclient.grpc as mod
+
+        c = mod.InferenceServerClient(gpu_server.grpc_url)
+    c.unregister_cuda_shared_memory()
+    a = np.arange(16, dtype=np.int32)
+    b = np.ones(16, dtype=np.int32)
+    hin = hipshm.create_shared_memory_region("input_data", 128, 0)
+    hout = hipshm.create_shared_memory_region("output_data", 128, 0)
+    try:
+        hipshm.set_shared_memory_region(hin, [a, b])
+        c.register_cuda_shared_memory("input_data", hipshm.get_raw_handle(hin), 0, 128)
+        c.register_cuda_shared_memory("output_data", hipshm.get_raw_handle(hout), 0, 128)
+        st = c.get_cuda_shared_memory_status()
+        names = {r["name"] for r in st} if proto == "http" else set(st.regions.keys())
+        assert names == {"input_data", "output_data"}
+        i0 = mod.InferInput("INPUT0", [1, 16], "INT32").set_shared_memory("input_data", 64)
+        i1 = mod.InferInput("INPUT1", [1, 16], "INT32").set_shared_memory("input_data", 64, offset=64)
+        o0 = mod.InferRequestedOutput("OUTPUT0")
+        o0.set_shared_memory("output_data", 64)
+        o1 = mod.InferRequestedOutput("OUTPUT1")
+        o1.set_shared_memory("output_data", 64, offset=64)
+        r = c.infer("simple", [i0, i1], outputs=[o0, o1])
+        assert r.get_output("OUTPUT0") is not None
+        np.testing.assert_array_equal(hipshm.get_contents_as_numpy(hout, np.int32, [1, 16]), (a + b).reshape(1, 16))
+        np.testing.assert_array_equal(hipshm.get_contents_as_numpy(hout, np.int32, [1, 16], offset=64),
+                                      (a - b).reshape(1, 16))
+    finally:
+        c.unregister_cuda_shared_memory()
+        hipshm.destroy_shared_memory_region(hin)
+        hipshm.destroy_shared_memory_region(hout)
+        c.close()
+
+
+def test_simple_string_over_grpc_hipshm(hipshm, gpu_server):
+    """BASELINE config 2: BYTES tensors over gRPC with device shared-memory I/O."""
+    import tritonclient.grpc as mod
+    import tritonclient.utils as utils
+
+    in0 = np.array([str(x).encode() for x in range(16)], dtype=object).reshape(1, 16)
+    in1 = np.array([b"1"] * 16, dtype=object).reshape(1, 16)
+    s0, s1 = utils.serialize_byte_tensor(in0), utils.serialize_byte_tensor(in1)
+    n0, n1 = utils.serialized_byte_size(s0), utils.serialized_byte_size(s1)
+    hin = hipshm.create_shared_memory_region("sin", n0 + n1, 0)
+    hout = hipshm.create_shared_memory_region("sout", 512, 0)
+    with mod.InferenceServerClient(gpu_server.grpc_url) as c:
+        try:
+            hipshm.set_shared_memory_region(hin, [s0, s1])
+            c.register_cuda_shared_memory("sin", hipshm.get_raw_handle(hin), 0, n0 + n1)
+            c.register_cuda_shared_memory("sout", hipshm.get_raw_handle(hout), 0, 512)
+            i0 = mod.InferInput("INPUT0", [1, 16], "BYTES").set_shared_memory("sin", n0)
+            i1 = mod.InferInput("INPUT1", [1, 16], "BYTES").set_shared_memory("sin", n1, offset=n0)
+            o0 = mod.InferRequestedOutput("OUTPUT0")
+            o0.set_shared_memory("sout", 256)
+            o1 = mod.InferRequestedOutput("OUTPUT1")
+            o1.set_shared_memory("sout", 256, offset=256)
+            c.infer("simple_string", [i0, i1], outputs=[o0, o1])
+            out0 = hipshm.get_contents_as_numpy(hout, np.object_, [1, 16])
+            out1 = hipshm.get_contents_as_numpy(hout, np.object_, [1, 16], offset=256)
+            assert [int(x) for x in out0.reshape(-1)] == list(range(1, 17))
+            assert [int(x) for x in out1.reshape(-1)] == list(range(-1, 15))
+        finally:
+            c.unregister_cuda_shared_memory()
+            hipshm.destroy_shared_memory_region(hin)
+            hipshm.destroy_shared_memory_region(hout)
+
+
+def test_resnet50_zero_copy_vs_wire(hipshm, gpu_server):
+    """BASELINE config 3: ResNet-50 fp16 batch 8, HIP preprocessing writes into
+    the hipshm input region, logits land in the hipshm output region; the wire
+    path must give the same answer."""
+    import torch
+    import tritonclient.grpc as mod
+    from triton_client_amd.ops.preprocess import Preprocessor
+
+    rng = np.random.default_rng(1)
+    images = [rng.integers(0, 256, size=(256 + 16 * i, 320, 3), dtype=np.uint8) for i in range(8)]
+    in_bytes = 8 * 3 * 224 * 224 * 2
+    out_bytes = 8 * 1000 * 4
+    hin = hipshm.create_shared_memory_region("rn_in", in_bytes, 0)
+    hout = hipshm.create_shared_memory_region("rn_out", out_bytes, 0)
+    pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=0)
+    pre(images, hin)
+    with mod.InferenceServerClient(gpu_server.grpc_url) as c:
+        try:
+            c.register_cuda_shared_memory("rn_in", hipshm.get_raw_handle(hin), 0, in_bytes)
+            c.register_cuda_shared_memory("rn_out", hipshm.get_raw_handle(hout), 0, out_bytes)
+            i0 = mod.InferInput("input", [8, 3, 224, 224], "FP16").set_shared_memory("rn_in", in_bytes)
+            o0 = mod.InferRequestedOutput("output")
+            o0.set_shared_memory("rn_out", out_bytes)
+            for _ in range(3):  # second/third call replay the captured HIP graph
+                c.infer("resnet50", [i0], outputs=[o0])
+            shm_logits = hipshm.get_contents_as_numpy(hout, np.float32, [8, 1000])
+            x = hipshm.get_contents_as_numpy(hin, np.float16, [8, 3, 224, 224])
+            wire_in = mod.InferInput("input", [8, 3, 224, 224], "FP16").set_data_from_numpy(x)
+            wire = c.infer("resnet50", [wire_in]).as_numpy("output")
+            assert np.isfinite(shm_logits).all()
+            np.testing.assert_allclose(shm_logits, wire, rtol=2e-2, atol=2e-2)
+            cls = c.infer("resnet50", [wire_in], outputs=[mod.InferRequestedOutput("output", class_count=3)])
+            top = cls.as_numpy("output")
+            assert top.shape == (8, 3)
+            score, idx, label = top[0][0].decode().split(":")
+            assert int(idx) == int(np.argmax(wire[0])) and label == f"class_{idx}"
+            assert abs(float(score) - float(wire[0].max())) < 5e-2
+        finally:
+            c.unregister_cuda_shared_memory()
+            hipshm.destroy_shared_memory_region(hin)
+            hipshm.destroy_shared_memory_region(hout)
+            pre.close()

@@ -1,0 +1,184 @@
+"""Numerics of the hand-written HIP kernels against plain fp32 / Pillow /
+numpy references."""
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    return torch
+
+
+@pytest.mark.parametrize("src_hw,channels", [((375, 500), 3), ((224, 224), 3), ((100, 130), 3), ((600, 450), 1),
+                                             ((300, 300), 4)])
+@pytest.mark.parametrize("layout", ["NCHW", "NHWC"])
+def test_preprocess_matches_pillow_bit_exact(torch, src_hw, channels, layout):
+    from triton_client_amd.ops.preprocess import Preprocessor, reference_preprocess
+
+    rng = np.random.default_rng(hash((src_hw, channels)) & 0xFFFF)
+    shape = src_hw + ((channels,) if channels > 1 else ())
+    imgs = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(3)]
+    pre = Preprocessor(224, 224, 3, layout, "FP32", scaling="NONE", resize="pil", device=0)
+    out_shape = (3, 3, 224, 224) if layout == "NCHW" else (3, 224, 224, 3)
+    out = torch.zeros(out_shape, device="cuda:0", dtype=torch.float32)
+    pre(imgs, out)
+    got = out.cpu().numpy()
+    for i, im in enumerate(imgs):
+        ref = reference_preprocess(im, 224, 224, 3, layout, np.float32, "NONE", "pil")
+        np.testing.assert_array_equal(got[i], ref)
+    pre.close()
+
+
+@pytest.mark.parametrize("dtype,np_dtype,scaling", [("FP16", np.float16, "INCEPTION"), ("FP32", np.float32, "VGG"),
+                                                    ("INT8", np.int8, "VGG"), ("UINT8", np.uint8, "NONE"),
+                                                    ("BF16", None, "INCEPTION"),
+                                                    ("FP32", np.float32, ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)))])
+def test_preprocess_scaling_and_cast(torch, dtype, np_dtype, scaling):
+    from triton_client_amd.ops.preprocess import Preprocessor, reference_preprocess
+
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, size=(333, 517, 3), dtype=np.uint8) for _ in range(2)]
+    pre = Preprocessor(299, 299, 3, "NCHW", dtype, scaling=scaling, resize="pil", device=0)
+    tdt = {"FP16": torch.float16, "FP32": torch.float32, "INT8": torch.int8, "UINT8": torch.uint8,
+           "BF16": torch.bfloat16}[dtype]
+    out = torch.zeros((2, 3, 299, 299), device="cuda:0", dtype=tdt)
+    pre(imgs, out)
+    got = out.float().cpu().numpy()
+    for i, im in enumerate(imgs):
+        ref32 = reference_preprocess(im, 299, 299, 3, "NCHW", np.float32, scaling, "pil")
+        if dtype == "BF16":
+            ref = torch.from_numpy(ref32).to(torch.bfloat16).float().numpy()
+            np.testing.assert_allclose(got[i], ref, rtol=0, atol=1e-2)
+        elif np_dtype in (np.int8, np.uint8):
+            ref = reference_preprocess(im, 299, 299, 3, "NCHW", np_dtype, scaling, "pil").astype(np.float32)
+            assert np.abs(got[i] - ref).max() <= 1  # rint ties may differ by one step
+        else:
+            ref = ref32.astype(np_dtype).astype(np.float32)
+            np.testing.assert_allclose(got[i], ref, rtol=1e-3, atol=1e-3)
+    pre.close()
+
+
+def test_preprocess_gray_bgr_cv_and_big_downscale(torch):
+    from triton_client_amd.ops.preprocess import Preprocessor, reference_preprocess
+
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    # RGB -> L output, BGR input order
+    pre = Preprocessor(224, 224, 1, "NCHW", "FP32", scaling="VGG", resize="pil", device=0)
+    out = torch.zeros((1, 1, 224, 224), device="cuda:0")
+    pre([im], out, bgr=True)
+    ref = reference_preprocess(im, 224, 224, 1, "NCHW", np.float32, "VGG", "pil", bgr=True)
+    np.testing.assert_array_equal(out.cpu().numpy()[0], ref)
+    pre.close()
+    # OpenCV-style 2-tap tables
+    pre = Preprocessor(224, 224, 3, "NHWC", "FP32", scaling="NONE", resize="cv", device=0)
+    out = torch.zeros((1, 224, 224, 3), device="cuda:0")
+    pre([im], out)
+    ref = reference_preprocess(im, 224, 224, 3, "NHWC", np.float32, "NONE", "cv")
+    np.testing.assert_array_equal(out.cpu().numpy()[0], ref)
+    pre.close()
+    # 4000x3000 -> 224: the tile height shrinks so the LDS tile still fits
+    big = rng.integers(0, 256, size=(3000, 4000, 3), dtype=np.uint8)
+    pre = Preprocessor(224, 224, 3, "NCHW", "FP32", scaling="NONE", resize="pil", device=0, max_image_bytes=64 << 20)
+    out = torch.zeros((1, 3, 224, 224), device="cuda:0")
+    pre([big], out)
+    ref = reference_preprocess(big, 224, 224, 3, "NCHW", np.float32, "NONE", "pil")
+    np.testing.assert_array_equal(out.cpu().numpy()[0], ref)
+    # upscale
+    small = rng.integers(0, 256, size=(60, 90, 3), dtype=np.uint8)
+    pre([small], out)
+    ref = reference_preprocess(small, 224, 224, 3, "NCHW", np.float32, "NONE", "pil")
+    np.testing.assert_array_equal(out.cpu().numpy()[0], ref)
+    pre.close()
+
+
+def test_bytes_pack_index_gather(torch):
+    import tritonclient.utils as utils
+    from triton_client_amd.ops import codec
+
+    rng = np.random.default_rng(7)
+    items = [bytes(rng.integers(0, 256, size=int(n), dtype=np.uint8)) for n in rng.integers(0, 200, size=3000)]
+    items[5] = b""
+    items[6] = b""
+    items += [bytes(rng.integers(0, 256, size=100000, dtype=np.uint8))]  # one element larger than the LDS chunk
+    wire = utils.serialize_byte_tensor(np.array(items, dtype=object)).item()
+    payload = np.frombuffer(b"".join(items), dtype=np.uint8)
+    offs = np.zeros(len(items) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(b) for b in items])
+    d_payload = torch.from_numpy(payload.copy()).cuda()
+    d_offs = torch.from_numpy(offs).cuda()
+    packed = codec.bytes_pack(d_payload, d_offs)
+    assert bytes(packed.cpu().numpy()) == wire
+    lens = torch.from_numpy(np.diff(offs).astype(np.int32)).cuda()
+    packed2 = codec.bytes_pack_from_lengths(d_payload, lens)
+    assert bytes(packed2.cpu().numpy()) == wire
+    scan = codec.lengths_to_offsets(lens, add_each=4).cpu().numpy()
+    np.testing.assert_array_equal(scan, np.concatenate([[0], np.cumsum(np.diff(offs) + 4)]))
+    # index (unpack) on the GPU
+    o, l = codec.bytes_index(packed, len(items))
+    o, l = o.cpu().numpy(), l.cpu().numpy()
+    np.testing.assert_array_equal(l, np.diff(offs))
+    np.testing.assert_array_equal(o, offs[:-1] + 4 * (np.arange(len(items)) + 1))
+    # fewer elements than the stream holds
+    o2, l2 = codec.bytes_index(packed, 10)
+    assert len(o2) == 10
+    # gather into fixed pitch rows
+    rows = codec.bytes_gather(packed, torch.from_numpy(o[:50]).cuda(), torch.from_numpy(l[:50]).cuda(), 64)
+    rows = rows.cpu().numpy()
+    for i in range(50):
+        exp = items[i][:64].ljust(64, b"\0")
+        assert bytes(rows[i]) == exp
+    # malformed stream
+    bad = torch.from_numpy(np.frombuffer(struct.pack("<I", 100) + b"abc", dtype=np.uint8).copy()).cuda()
+    with pytest.raises(ValueError):
+        codec.bytes_index(bad, 5)
+
+
+def test_bf16_kernels(torch):
+    import tritonclient.utils as utils
+    from triton_client_amd.ops import codec
+
+    x = torch.randn(1 << 20, device="cuda") * 100
+    x[:4] = torch.tensor([0.0, -0.0, float("inf"), 1.00390625 + 2 ** -9])
+    trunc = codec.fp32_to_bf16(x).cpu().numpy().view(np.uint16)
+    ref = np.frombuffer(utils.serialize_bf16_tensor(x.cpu().numpy()).item(), dtype=np.uint16)
+    np.testing.assert_array_equal(trunc, ref)
+    rne = codec.fp32_to_bf16(x, round_nearest=True)
+    np.testing.assert_array_equal(rne.cpu().numpy().view(np.uint16),
+                                  x.to(torch.bfloat16).view(torch.int16).cpu().numpy().view(np.uint16))
+    back = codec.bf16_to_fp32(rne)
+    assert torch.equal(back, x.to(torch.bfloat16).float())
+    odd = torch.randn(1027, device="cuda")
+    assert torch.equal(codec.bf16_to_fp32(codec.fp32_to_bf16(odd, True)), odd.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("dt", ["float32", "float16", "bfloat16"])
+def test_topk_and_classification_strings(torch, dt):
+    from triton_client_amd.ops import classification
+
+    tdt = getattr(torch, dt)
+    logits = (torch.randn(16, 1000, device="cuda") * 5).to(tdt)
+    logits[3, 10] = logits[3, 20] = 50.0  # tie -> lowest index first
+    vals, idx = classification.topk(logits, 5)
+    ref = logits.float().cpu().numpy()
+    order = np.argsort(-ref, axis=1, kind="stable")[:, :5]
+    np.testing.assert_array_equal(idx.cpu().numpy(), order)
+    np.testing.assert_array_equal(vals.cpu().numpy(), np.take_along_axis(ref, order, axis=1))
+    labels = [f"label {i}" for i in range(1000)]
+    table = classification.LabelTable(labels, logits.device)
+    buf, n = classification.classification_bytes(vals, idx, table)
+    import tritonclient.utils as utils
+
+    got = utils.deserialize_bytes_tensor(bytes(buf[:n].cpu().numpy()))
+    exp = classification.topk_strings(logits, 5, labels).reshape(-1)
+    assert len(got) == 80
+    for g, e in zip(got, exp):
+        gs, gi, gl = g.decode().split(":")
+        es, ei, el = e.decode().split(":")
+        assert (gi, gl) == (ei, el) and abs(float(gs) - float(es)) <= 1.1e-6, (g, e)

@@ -71,6 +71,8 @@ class InferResult:
                 field = _TYPED_FIELDS.get(datatype)
                 values = getattr(output.contents, field) if field else ()
                 if len(values) == 0:
+                    if "shared_memory_region" in output.parameters:
+                        return None  # the data was written to the caller's region, not sent
                     arr = np.empty(0, dtype=triton_to_np_dtype(datatype))
                 elif datatype == "BYTES":
                     arr = np.empty(len(values), dtype=np.object_)

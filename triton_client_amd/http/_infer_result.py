@@ -87,8 +87,10 @@ class InferResult:
                         arr = deserialize_bf16_tensor(chunk)
                     else:
                         arr = np.frombuffer(chunk, dtype=triton_to_np_dtype(datatype))
-            else:
+            elif "data" in output:
                 arr = np.array(output["data"], dtype=triton_to_np_dtype(datatype))
+            else:
+                return None  # written to a shared memory region: nothing travelled in the response
             return arr.reshape(output["shape"])
         return None
 
