@@ -239,7 +239,9 @@ def main():
 
     from triton_client_amd.server import spawn_server
 
-    server = spawn_server(models=[args.model], gpu=device)
+    server = spawn_server(models=[args.model], gpu=device,
+                          extra_args=["--grpc-workers", str(max(32, 2 * args.concurrency)), "--http-workers",
+                                      str(max(16, 2 * args.concurrency))])
     try:
         url = server.grpc_url if args.protocol == "grpc" else server.http_url
         main_result = measure(args, url, device, dist, f"{args.protocol}+{args.shared_memory}shm")

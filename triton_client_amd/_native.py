@@ -69,6 +69,34 @@ def core():
     return _core
 
 
+def _preload_torch_hip_runtime():
+    """Make PyTorch-ROCm and our library share ONE HIP runtime.
+
+    The torch wheel bundles its own ``libamdhip64.so`` (SONAME
+    ``libamdhip64.so.7``).  If ``/opt/rocm/lib/libamdhip64.so.7`` were mapped
+    first, torch would later map its private copy as well and the process
+    would hold two HIP/HSA runtimes - the second one then reports "no
+    ROCm-capable device".  Mapping torch's copy first makes our
+    ``DT_NEEDED libamdhip64.so.7`` resolve to it by SONAME.
+    """
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def hip():
     """ctypes handle of libtca_hip.so with prototypes installed by :mod:`ops._bind`."""
     global _hip
@@ -77,6 +105,7 @@ def hip():
     with _lock:
         if _hip is not None:
             return _hip
+        _preload_torch_hip_runtime()
         lib = ctypes.CDLL(_ensure("hip", "libtca_hip.so"))
         from .ops import _bind
 

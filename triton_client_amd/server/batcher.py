@@ -49,12 +49,37 @@ class DynamicBatcher:
         self._held = None
         self._stop = False
         self._static = {}
+        # at most this many batches are enqueued on the GPU stream at once: while
+        # they run, arriving requests accumulate into ONE larger next batch
+        # instead of a train of small ones
+        self._inflight = threading.Semaphore(int(getattr(self.model, "max_inflight_batches", 2)))
+        self._prewarm()
         self._threads = [
             threading.Thread(target=self._batch_loop, name="tca-batcher", daemon=True),
             threading.Thread(target=self._complete_loop, name="tca-completer", daemon=True),
         ]
         for t in self._threads:
             t.start()
+
+    def _prewarm(self):
+        """Capture the model's HIP graphs for the merged batch sizes up front so
+        no request ever waits for a capture."""
+        import torch
+
+        model = self.model
+        sizes = [b for b in getattr(model, "warmup_batches", ()) if b <= self.max_batch]
+        if not sizes or not getattr(model, "use_graphs", False):
+            return
+        spec = model.inputs[0]
+        from ..utils import triton_to_np_dtype
+
+        np_dt = triton_to_np_dtype(spec.datatype)
+        t_dt = torch.from_numpy(np.zeros(1, dtype=np_dt)).dtype
+        for b in sizes:
+            sbuf, obuf = self._static_buffers(b, spec.name, t_dt, tuple(spec.dims), model.outputs[0].name)
+            sbuf.zero_()
+            model.execute({spec.name: sbuf, "__out__" + model.outputs[0].name: obuf}, None)
+        model.stream.synchronize()
 
     def stop(self):
         self._stop = True
@@ -78,12 +103,18 @@ class DynamicBatcher:
             return None
         group, total = [first], first.batch
         deadline = time.perf_counter() + self.delay_s
+        have_slot = False
         while total < self.max_batch:
             try:
                 remaining = deadline - time.perf_counter()
                 nxt = self.q.get_nowait() if remaining <= 0 else self.q.get(timeout=remaining)
             except queue.Empty:
-                break
+                # the queue delay has passed: launch as soon as the GPU has room,
+                # and keep absorbing requests that arrive while it does not
+                if have_slot or self._inflight.acquire(timeout=0.0005):
+                    have_slot = True
+                    break
+                continue
             if nxt is None:
                 self._stop = True
                 break
@@ -92,6 +123,8 @@ class DynamicBatcher:
                 break
             group.append(nxt)
             total += nxt.batch
+        if not have_slot:
+            self._inflight.acquire()
         return group, total
 
     def _batch_loop(self):
@@ -105,13 +138,16 @@ class DynamicBatcher:
             group, total = got
             try:
                 self._launch(group, total)
+                continue
             except (ServerError, ModelError) as e:
+                self._inflight.release()
                 err = e if isinstance(e, ServerError) else ServerError(str(e), 400)
                 for it in group:
                     it.error = err
                     it.stats.record_fail(time.perf_counter_ns() - it.t_arrive)
                     it.done.set()
             except Exception as e:  # keep serving after an unexpected failure
+                self._inflight.release()
                 err = ServerError(f"internal error while executing '{self.model.name}': {type(e).__name__}: {e}", 500)
                 for it in group:
                     it.error = err
@@ -236,6 +272,7 @@ class DynamicBatcher:
                 break
             event, pending, total, t_exec, t_enq = entry
             event.synchronize()
+            self._inflight.release()
             t_done = time.perf_counter_ns()
             out_specs = {t.name: t for t in self.model.outputs}
             for it, dev_inputs, result in pending:
