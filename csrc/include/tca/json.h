@@ -106,6 +106,9 @@ class Value {
   }
   Value& operator[](size_t i) { return arr_[i]; }
   const Value& operator[](size_t i) const { return arr_[i]; }
+  // int overloads: a literal 0 would otherwise be ambiguous with the const char* key form
+  Value& operator[](int i) { return arr_[static_cast<size_t>(i)]; }
+  const Value& operator[](int i) const { return arr_[static_cast<size_t>(i)]; }
   Value& Append(Value v) {
     if (kind_ != Kind::Array) { *this = Array(); }
     arr_.push_back(std::move(v));

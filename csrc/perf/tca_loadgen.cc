@@ -1,0 +1,214 @@
+// Native load generator core: keeps `-c N` inference requests outstanding over
+// HTTP from ONE epoll thread (no interpreter in the loop) and reports
+// throughput and latency percentiles as a JSON line.  The Python analyzer uses
+// it for high concurrency levels where per-request Python cost would bound the
+// offered load (`python -m triton_client_amd.perf --native`).
+//
+//   tca_loadgen -u host:port -m model [-x version] -c 64 -d 5.0 --warmup 1.0
+//       --shape NAME:DATATYPE:d0,d1,...      wire tensors (zero filled)
+//       --shm-input NAME:DATATYPE:dims:REGION:BYTES[:OFFSET]   registered shm input
+//       --shm-output NAME:REGION:BYTES[:OFFSET]
+//       -b batch (only scales the reported infer/sec)
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+#include <sstream>
+#include <thread>
+
+#include "tca/codec.h"
+#include "tca/http_client.h"
+
+namespace tc = tca::client;
+
+namespace {
+
+std::vector<std::string> Split(const std::string& s, char sep) {
+  std::vector<std::string> out;
+  std::stringstream ss(s);
+  std::string item;
+  while (std::getline(ss, item, sep)) out.push_back(item);
+  return out;
+}
+
+std::vector<int64_t> Dims(const std::string& s) {
+  std::vector<int64_t> out;
+  for (const auto& d : Split(s, ',')) out.push_back(std::atoll(d.c_str()));
+  return out;
+}
+
+uint64_t NowNs() {
+  return static_cast<uint64_t>(
+      std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+
+struct Slot {
+  std::vector<std::unique_ptr<tc::InferInput>> inputs;
+  std::vector<std::unique_ptr<tc::InferRequestedOutput>> outputs;
+  std::vector<std::vector<uint8_t>> storage;
+  std::vector<tc::InferInput*> in_ptrs;
+  std::vector<const tc::InferRequestedOutput*> out_ptrs;
+  uint64_t t0 = 0;
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string url = "localhost:8000", model, version;
+  int concurrency = 1, batch = 1;
+  double duration = 5.0, warmup = 1.0;
+  std::vector<std::string> shapes, shm_in, shm_out;
+  for (int i = 1; i < argc; ++i) {
+    auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+    if (!std::strcmp(argv[i], "-u")) url = next();
+    else if (!std::strcmp(argv[i], "-m")) model = next();
+    else if (!std::strcmp(argv[i], "-x")) version = next();
+    else if (!std::strcmp(argv[i], "-c")) concurrency = std::atoi(next());
+    else if (!std::strcmp(argv[i], "-b")) batch = std::atoi(next());
+    else if (!std::strcmp(argv[i], "-d")) duration = std::atof(next());
+    else if (!std::strcmp(argv[i], "--warmup")) warmup = std::atof(next());
+    else if (!std::strcmp(argv[i], "--shape")) shapes.push_back(next());
+    else if (!std::strcmp(argv[i], "--shm-input")) shm_in.push_back(next());
+    else if (!std::strcmp(argv[i], "--shm-output")) shm_out.push_back(next());
+    else { std::cerr << "unknown argument " << argv[i] << std::endl; return 2; }
+  }
+  if (model.empty() || concurrency < 1) { std::cerr << "usage: tca_loadgen -u url -m model -c N ..." << std::endl; return 2; }
+  std::unique_ptr<tc::InferenceServerHttpClient> client;
+  tca::Error e = tc::InferenceServerHttpClient::Create(&client, url);
+  if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+
+  // one request template per slot; `{slot}` in region names is replaced by the slot index
+  std::vector<std::unique_ptr<Slot>> slots;
+  for (int s = 0; s < concurrency; ++s) {
+    std::unique_ptr<Slot> slot(new Slot());
+    auto subst = [&](std::string name) {
+      const size_t pos = name.find("{slot}");
+      if (pos != std::string::npos) name.replace(pos, 6, std::to_string(s));
+      return name;
+    };
+    for (const auto& spec : shapes) {
+      auto parts = Split(spec, ':');
+      if (parts.size() != 3) { std::cerr << "bad --shape " << spec << std::endl; return 2; }
+      auto dims = Dims(parts[2]);
+      tc::InferInput* in = nullptr;
+      e = tc::InferInput::Create(&in, parts[0], dims, parts[1]);
+      if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+      const int64_t count = tca::ElementCount(dims);
+      size_t bytes = static_cast<size_t>(count) * tca::DataTypeByteSize(parts[1]);
+      if (parts[1] == "BYTES") bytes = static_cast<size_t>(count) * 5;  // "0" per element
+      slot->storage.emplace_back(bytes, 0);
+      if (parts[1] == "BYTES")
+        for (int64_t k = 0; k < count; ++k) { slot->storage.back()[k * 5] = 1; slot->storage.back()[k * 5 + 4] = '0'; }
+      in->AppendRaw(slot->storage.back().data(), bytes);
+      slot->inputs.emplace_back(in);
+      slot->in_ptrs.push_back(in);
+    }
+    for (const auto& spec : shm_in) {
+      auto parts = Split(spec, ':');
+      if (parts.size() < 5) { std::cerr << "bad --shm-input " << spec << std::endl; return 2; }
+      tc::InferInput* in = nullptr;
+      e = tc::InferInput::Create(&in, parts[0], Dims(parts[2]), parts[1]);
+      if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+      in->SetSharedMemory(subst(parts[3]), std::strtoull(parts[4].c_str(), nullptr, 10),
+                          parts.size() > 5 ? std::strtoull(parts[5].c_str(), nullptr, 10) : 0);
+      slot->inputs.emplace_back(in);
+      slot->in_ptrs.push_back(in);
+    }
+    for (const auto& spec : shm_out) {
+      auto parts = Split(spec, ':');
+      if (parts.size() < 3) { std::cerr << "bad --shm-output " << spec << std::endl; return 2; }
+      tc::InferRequestedOutput* out = nullptr;
+      tc::InferRequestedOutput::Create(&out, parts[0]);
+      out->SetSharedMemory(subst(parts[1]), std::strtoull(parts[2].c_str(), nullptr, 10),
+                           parts.size() > 3 ? std::strtoull(parts[3].c_str(), nullptr, 10) : 0);
+      slot->outputs.emplace_back(out);
+      slot->out_ptrs.push_back(out);
+    }
+    slots.push_back(std::move(slot));
+  }
+
+  tc::InferOptions options(model);
+  options.model_version_ = version;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<uint64_t> latencies;
+  latencies.reserve(1 << 20);
+  std::atomic<bool> measuring{false}, stopping{false};
+  std::atomic<uint64_t> errors{0};
+  int outstanding = 0;
+  std::string first_error;
+
+  std::function<void(int)> issue = [&](int s) {
+    Slot* slot = slots[s].get();
+    slot->t0 = NowNs();
+    tca::Error se = client->AsyncInfer(
+        [&, s](tc::InferResult* r) {
+          const uint64_t t1 = NowNs();
+          tca::Error status = r->RequestStatus();
+          delete r;
+          bool again;
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!status.IsOk()) {
+              ++errors;
+              if (first_error.empty()) first_error = status.Message();
+            } else if (measuring.load()) {
+              latencies.push_back(t1 - slots[s]->t0);
+            }
+            again = !stopping.load();
+            if (!again && --outstanding == 0) cv.notify_all();
+          }
+          if (again) issue(s);  // re-submitted from the reactor thread: zero idle time per slot
+        },
+        options, slot->in_ptrs, slot->out_ptrs);
+    if (!se.IsOk()) {
+      std::lock_guard<std::mutex> lk(mu);
+      ++errors;
+      if (first_error.empty()) first_error = se.Message();
+      if (--outstanding == 0) cv.notify_all();
+    }
+  };
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    outstanding = concurrency;
+  }
+  for (int s = 0; s < concurrency; ++s) issue(s);
+  std::this_thread::sleep_for(std::chrono::duration<double>(warmup));
+  const uint64_t start = NowNs();
+  measuring.store(true);
+  std::this_thread::sleep_for(std::chrono::duration<double>(duration));
+  measuring.store(false);
+  const uint64_t end = NowNs();
+  stopping.store(true);
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait_for(lk, std::chrono::seconds(30), [&] { return outstanding == 0; });
+  }
+  std::vector<uint64_t> lat;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    lat = latencies;
+  }
+  std::sort(lat.begin(), lat.end());
+  auto pct = [&](double p) -> double {
+    if (lat.empty()) return 0.0;
+    const size_t idx = std::min(lat.size() - 1, static_cast<size_t>(p / 100.0 * (lat.size() - 1) + 0.5));
+    return lat[idx] / 1e3;
+  };
+  double sum = 0;
+  for (uint64_t v : lat) sum += static_cast<double>(v);
+  const double secs = (end - start) / 1e9;
+  std::printf(
+      "{\"requests\": %zu, \"errors\": %llu, \"duration_s\": %.4f, \"requests_per_sec\": %.2f, \"infer_per_sec\": %.2f, "
+      "\"avg_us\": %.1f, \"p50_us\": %.1f, \"p90_us\": %.1f, \"p95_us\": %.1f, \"p99_us\": %.1f, \"concurrency\": %d, "
+      "\"first_error\": \"%s\"}\n",
+      lat.size(), static_cast<unsigned long long>(errors.load()), secs, lat.size() / secs, lat.size() * batch / secs,
+      lat.empty() ? 0.0 : sum / lat.size() / 1e3, pct(50), pct(90), pct(95), pct(99), concurrency,
+      first_error.substr(0, 200).c_str());
+  return 0;
+}

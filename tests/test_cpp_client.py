@@ -1,0 +1,75 @@
+"""Builds the native client (``make -C csrc``) and runs its unit tests, the
+server-backed suite, the timeout / leak tools and the C++ examples against the
+in-repo server."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "build", "bin")
+
+
+@pytest.fixture(scope="module")
+def built():
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no host C++ toolchain")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "csrc"), "-j8", f"BUILD={os.path.join(ROOT, 'build')}",
+                           "lib", "tests", "perf", "host_examples"], stdout=subprocess.DEVNULL)
+    return BIN
+
+
+def _run(cmd, timeout=180):
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, f"{' '.join(cmd)}\n{p.stdout[-3000:]}\n{p.stderr[-3000:]}"
+    return p.stdout
+
+
+def test_cc_unit(built):
+    out = _run([os.path.join(built, "cc_unit_test")])
+    assert "0 failed" in out
+
+
+def test_cc_client_suite(built, server):
+    out = _run([os.path.join(built, "cc_client_test"), "-u", server.http_url])
+    assert "0 failed" in out and "AsyncInferMulti" in out
+
+
+def test_cc_timeout_and_leak_tools(built, server):
+    assert "timeouts reported" in _run([os.path.join(built, "client_timeout_test"), "-u", server.http_url, "-t",
+                                        "100000"])
+    assert "requests completed" in _run([os.path.join(built, "client_timeout_test"), "-u", server.http_url, "-t",
+                                         "3000000"])
+    assert "PASS" in _run([os.path.join(built, "memory_leak_test"), "-u", server.http_url, "-r", "200"])
+    assert "PASS" in _run([os.path.join(built, "memory_leak_test"), "-u", server.http_url, "-r", "200", "-R"])
+
+
+def test_native_loadgen(built, server):
+    import json
+
+    out = _run([os.path.join(built, "tca_loadgen"), "-u", server.http_url, "-m", "simple", "-c", "8", "-d", "1.0",
+                "--warmup", "0.2", "--shape", "INPUT0:INT32:1,16", "--shape", "INPUT1:INT32:1,16"])
+    stats = json.loads(out.strip().splitlines()[-1])
+    assert stats["errors"] == 0 and stats["requests"] > 100 and stats["p99_us"] >= stats["p50_us"] > 0
+
+
+CPP_EXAMPLES = [
+    "simple_http_infer_client", "simple_http_async_infer_client", "simple_http_string_infer_client",
+    "simple_http_shm_client", "simple_http_sequence_sync_infer_client", "simple_http_health_metadata",
+    "simple_http_model_control", "reuse_infer_objects_client", "image_client", "ensemble_image_client",
+]
+
+
+@pytest.mark.parametrize("name", CPP_EXAMPLES)
+def test_cpp_examples(built, server, name):
+    exe = os.path.join(built, name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{name} not built")
+    args = [exe, "-u", server.http_url]
+    if name == "image_client":
+        args += ["-m", "tiny_classifier", "-c", "3", "-s", "INCEPTION", "--synthetic", "2"]
+    elif name == "ensemble_image_client":
+        args += ["-c", "2", "--synthetic", "2"]
+    out = _run(args)
+    assert "PASS" in out

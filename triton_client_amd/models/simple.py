@@ -200,3 +200,87 @@ class RepeatInt32(Model):
                 time.sleep(wait / 1000.0)
 
         return responses()
+
+
+def _tiny_logits(x_nchw):
+    """Deterministic 10-class "classifier": class scores are weighted channel
+    means, so results are easy to verify from the client side."""
+    means = x_nchw.reshape(x_nchw.shape[0], x_nchw.shape[1], -1).mean(axis=2).astype(np.float32)  # [B, C]
+    c = means.shape[1]
+    weights = (np.arange(10, dtype=np.float32)[:, None] + 1.0) * (np.arange(c, dtype=np.float32)[None, :] - 0.5)
+    return means @ weights.T  # [B, 10]
+
+
+_TINY_LABELS = ["tench", "goldfish", "shark", "ray", "rooster", "hen", "ostrich", "finch", "robin", "owl"]
+
+
+@register
+class TinyClassifier(Model):
+    """CPU stand-in for an image classifier (NCHW FP32 in, FP32 vector out) so
+    that ``image_client`` runs without a GPU.  Contract as the reference's
+    ``image_client.py:59-150`` expects: one 3-dim input + batch, one FP32
+    vector output, labels for the classification extension."""
+
+    name = "tiny_classifier"
+    max_batch_size = 16
+    inputs = [TensorSpec("input", "FP32", [3, 224, 224], format="FORMAT_NCHW")]
+    outputs = [TensorSpec("output", "FP32", [10], label_filename="labels.txt")]
+    labels = _TINY_LABELS
+
+    def execute(self, inputs, ctx):
+        return {"output": _tiny_logits(inputs["input"])}
+
+
+@register
+class TinyClassifierNhwc(Model):
+    name = "tiny_classifier_nhwc"
+    max_batch_size = 16
+    inputs = [TensorSpec("input", "FP32", [224, 224, 3], format="FORMAT_NHWC")]
+    outputs = [TensorSpec("output", "FP32", [10], label_filename="labels.txt")]
+    labels = _TINY_LABELS
+
+    def execute(self, inputs, ctx):
+        return {"output": _tiny_logits(np.transpose(inputs["input"], (0, 3, 1, 2)))}
+
+
+@register
+class PreprocessEnsemble(Model):
+    """Ensemble taking encoded image files (JPEG/PNG/PPM bytes) as a BYTES
+    tensor: decode -> resize 224 + INCEPTION scaling -> ``tiny_classifier``.
+    The reference's ``ensemble_image_client`` talks to such a model
+    (``preprocess_inception_ensemble``, server side DALI preprocessing)."""
+
+    name = "preprocess_inception_ensemble"
+    platform = "ensemble"
+    max_batch_size = 16
+    inputs = [TensorSpec("INPUT", "BYTES", [1])]
+    outputs = [TensorSpec("OUTPUT", "FP32", [10], label_filename="labels.txt")]
+    labels = _TINY_LABELS
+
+    def execute(self, inputs, ctx):
+        import io
+
+        from PIL import Image
+
+        from ..ops.preprocess_ref import reference_preprocess
+
+        blobs = inputs["INPUT"].reshape(-1)
+        batch = []
+        for blob in blobs:
+            try:
+                img = Image.open(io.BytesIO(blob))
+                img.load()
+            except Exception as e:
+                raise ModelError(f"unable to decode image: {e}") from None
+            batch.append(reference_preprocess(np.asarray(img.convert("RGB")), 224, 224, 3, "NCHW", np.float32,
+                                              "INCEPTION", "pil"))
+        return {"OUTPUT": _tiny_logits(np.stack(batch))}
+
+    def config(self):
+        cfg = super().config()
+        cfg["ensemble_scheduling"] = {"step": [
+            {"model_name": "image_preprocess", "model_version": -1, "input_map": {"INPUT": "INPUT"},
+             "output_map": {"OUTPUT": "preprocessed"}},
+            {"model_name": "tiny_classifier", "model_version": -1, "input_map": {"input": "preprocessed"},
+             "output_map": {"output": "OUTPUT"}}]}
+        return cfg
