@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""System shared memory over HTTP: two tensors per region via offsets.
+(Reference: ``src/python/examples/simple_http_shm_client.py``.)"""
+from _common import parser
+from _shm_example import run_simple
+
+import tritonclient.http as client_module
+
+if __name__ == "__main__":
+    flags = parser(__doc__, 8000).parse_args()
+    client = client_module.InferenceServerClient(url=flags.url, verbose=flags.verbose)
+    run_simple(client_module, client, "system")
+    client.close()
+    print("PASS: system shared memory")

@@ -9,7 +9,7 @@ from . import simple  # noqa: F401  (registers the CPU models)
 from . import vision  # noqa: F401  (registers resnet50 & friends; torch is imported on load)
 
 DEFAULT_CPU_MODELS = (
-    "simple", "simple_string", "simple_identity", "custom_identity_int32", "onnx_int32_int32_int32",
+    "simple", "simple_int8", "simple_string", "simple_identity", "custom_identity_int32", "onnx_int32_int32_int32",
     "simple_sequence", "simple_dyna_sequence", "simple_string_dyna_sequence", "repeat_int32",
     "tiny_classifier", "tiny_classifier_nhwc", "preprocess_inception_ensemble",
 )

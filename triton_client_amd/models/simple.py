@@ -42,6 +42,21 @@ class Simple(Model):
 
 
 @register
+class SimpleInt8(Model):
+    """INT8 flavour of ``simple`` (reference
+    ``src/python/examples/grpc_explicit_int8_content_client.py:59``)."""
+
+    name = "simple_int8"
+    max_batch_size = 8
+    inputs = [TensorSpec("INPUT0", "INT8", [16]), TensorSpec("INPUT1", "INT8", [16])]
+    outputs = [TensorSpec("OUTPUT0", "INT8", [16]), TensorSpec("OUTPUT1", "INT8", [16])]
+
+    def execute(self, inputs, ctx):
+        a, b = inputs["INPUT0"], inputs["INPUT1"]
+        return {"OUTPUT0": (a + b).astype(np.int8), "OUTPUT1": (a - b).astype(np.int8)}
+
+
+@register
 class VersionedAddSub(Model):
     """Three versions; 2 and 3 return (sub, add) instead of (add, sub)
     (reference ``src/c++/tests/cc_client_test.cc:436-440``)."""

@@ -476,6 +476,9 @@ class InferenceCore:
             lm = self._loaded.get(name)
         if lm is None:
             raise ServerError(f"Request for unknown model: '{name}' is not found", 400)
+        if version and not version.isdigit():
+            raise ServerError(f"failed to get model version from specified version string '{version}' "
+                              "(details: stoll): the model version must be an integral number", 400)
         if version and version not in lm.model.versions:
             raise ServerError(f"Request for unknown model: '{name}' version {version} is not found", 400)
         return lm
