@@ -110,54 +110,69 @@ __device__ int FormatInt(int v, char* buf) {
   return n;
 }
 
-constexpr int kMaxEntries = 512;   // rows * k handled by the single formatting workgroup
+constexpr int kChunk = 512;        // entries formatted per pass of the single formatting workgroup
 constexpr int kHeadBytes = 64;     // "value:index" always fits
 
+// One workgroup walks the entries in chunks of kChunk: format heads into LDS,
+// serial scan of the chunk's lengths (<= 512 adds, cheaper than a barrier tree),
+// then every thread copies its elements.  `base` carries the running output
+// offset between chunks, so element order and offsets match a serial encoder.
+// Elements that would cross `out_cap` are not written; `out_size` always gets
+// the full size so the caller can tell.
 __global__ __launch_bounds__(kThreads) void ClassifyStringsKernel(
     const float* __restrict__ values, const int* __restrict__ indices, int entries, const uint8_t* __restrict__ labels,
     const uint32_t* __restrict__ label_offsets, int num_labels, uint8_t* __restrict__ out, uint64_t out_cap,
     uint64_t* __restrict__ out_size) {
-  __shared__ char heads[kMaxEntries][kHeadBytes];
-  __shared__ uint32_t head_len[kMaxEntries];
-  __shared__ uint32_t total_len[kMaxEntries];
-  __shared__ uint32_t start[kMaxEntries + 1];
-  for (int e = threadIdx.x; e < entries; e += kThreads) {
-    char* h = heads[e];
-    int n = FormatFixed6(values[e], h);
-    h[n++] = ':';
-    const int idx = indices[e];
-    n += FormatInt(idx, h + n);
-    uint32_t lab = 0;
-    if (labels != nullptr && idx >= 0 && idx < num_labels) lab = 1 + (label_offsets[idx + 1] - label_offsets[idx]);
-    head_len[e] = static_cast<uint32_t>(n);
-    total_len[e] = static_cast<uint32_t>(n) + lab;
-  }
+  __shared__ char heads[kChunk][kHeadBytes];
+  __shared__ uint32_t head_len[kChunk];
+  __shared__ uint32_t total_len[kChunk];
+  __shared__ uint64_t start[kChunk + 1];
+  __shared__ uint64_t base;
+  if (threadIdx.x == 0) base = 0;
   __syncthreads();
-  if (threadIdx.x == 0) {  // <= 1024 entries: a serial scan costs less than a barrier tree
-    uint32_t acc = 0;
-    for (int e = 0; e < entries; ++e) { start[e] = acc; acc += 4 + total_len[e]; }
-    start[entries] = acc;
-    *out_size = acc;
-  }
-  __syncthreads();
-  if (start[entries] > out_cap) return;  // caller checks out_size against its capacity
-  for (int e = threadIdx.x; e < entries; e += kThreads) {
-    uint8_t* p = out + start[e];
-    const uint32_t len = total_len[e];
-    p[0] = static_cast<uint8_t>(len);
-    p[1] = static_cast<uint8_t>(len >> 8);
-    p[2] = static_cast<uint8_t>(len >> 16);
-    p[3] = static_cast<uint8_t>(len >> 24);
-    p += 4;
-    for (uint32_t j = 0; j < head_len[e]; ++j) p[j] = static_cast<uint8_t>(heads[e][j]);
-    if (len > head_len[e]) {
-      p += head_len[e];
-      *p++ = ':';
-      const int idx = indices[e];
-      const uint8_t* l = labels + label_offsets[idx];
-      for (uint32_t j = 0; j + 1 < len - head_len[e]; ++j) p[j] = l[j];
+  for (int first = 0; first < entries; first += kChunk) {
+    const int count = min(kChunk, entries - first);
+    for (int e = threadIdx.x; e < count; e += kThreads) {
+      char* h = heads[e];
+      int n = FormatFixed6(values[first + e], h);
+      h[n++] = ':';
+      const int idx = indices[first + e];
+      n += FormatInt(idx, h + n);
+      uint32_t lab = 0;
+      if (labels != nullptr && idx >= 0 && idx < num_labels) lab = 1 + (label_offsets[idx + 1] - label_offsets[idx]);
+      head_len[e] = static_cast<uint32_t>(n);
+      total_len[e] = static_cast<uint32_t>(n) + lab;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint64_t acc = base;
+      for (int e = 0; e < count; ++e) { start[e] = acc; acc += 4 + total_len[e]; }
+      start[count] = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < count; e += kThreads) {
+      const uint32_t len = total_len[e];
+      if (start[e] + 4 + len > out_cap) continue;
+      uint8_t* p = out + start[e];
+      p[0] = static_cast<uint8_t>(len);
+      p[1] = static_cast<uint8_t>(len >> 8);
+      p[2] = static_cast<uint8_t>(len >> 16);
+      p[3] = static_cast<uint8_t>(len >> 24);
+      p += 4;
+      for (uint32_t j = 0; j < head_len[e]; ++j) p[j] = static_cast<uint8_t>(heads[e][j]);
+      if (len > head_len[e]) {
+        p += head_len[e];
+        *p++ = ':';
+        const int idx = indices[first + e];
+        const uint8_t* l = labels + label_offsets[idx];
+        for (uint32_t j = 0; j + 1 < len - head_len[e]; ++j) p[j] = l[j];
+      }
+    }
+    __syncthreads();  // heads / start are rewritten by the next chunk
+    if (threadIdx.x == 0) base = start[count];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) *out_size = base;
 }
 
 }  // namespace
@@ -194,7 +209,7 @@ int tca_classify_strings_launch(const float* values, const int* indices, int row
                                 uint64_t* out_size, void* stream) {
   const long long entries = static_cast<long long>(rows) * k;
   if (!values || !indices || !out || !out_size || entries <= 0) return -1;
-  if (entries > kMaxEntries) return -2;
+  if (entries > (1 << 20)) return -2;
   if (labels && !label_offsets) return -1;
   hipLaunchKernelGGL(ClassifyStringsKernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), values,
                      indices, static_cast<int>(entries), labels, label_offsets, num_labels, out, out_cap, out_size);

@@ -182,3 +182,28 @@ def test_topk_and_classification_strings(torch, dt):
         gs, gi, gl = g.decode().split(":")
         es, ei, el = e.decode().split(":")
         assert (gi, gl) == (ei, el) and abs(float(gs) - float(es)) <= 1.1e-6, (g, e)
+
+
+@pytest.mark.parametrize("rows,k,with_labels", [(128, 5, True), (128, 10, False), (3, 1000, True)])
+def test_classification_payload_many_entries(torch, rows, k, with_labels):
+    """More entries than one formatting pass holds (chunks of 512): element
+    order, offsets and the running size must match a serial host encoder."""
+    import tritonclient.utils as utils
+    from triton_client_amd.ops import classification
+
+    logits = torch.randn(rows, 1000, device="cuda") * 8
+    labels = [f"class-{i}" * (1 + i % 3) for i in range(1000)] if with_labels else None
+    table = classification.LabelTable(labels, logits.device) if with_labels else None
+    blob, shape = classification.classification_payload(logits, k, table)
+    assert shape == [rows, k]
+    got = utils.deserialize_bytes_tensor(blob)
+    exp = classification.topk_strings(logits, k, labels).reshape(-1)
+    assert len(got) == rows * k
+    for g, e in zip(got, exp):
+        gp, ep = g.decode().split(":"), e.decode().split(":")
+        assert gp[1:] == ep[1:] and abs(float(gp[0]) - float(ep[0])) <= 1.1e-6, (g, e)
+    # destination too small: size is still reported, nothing is written past the end
+    vals, idx = classification.topk(logits, k)
+    small = torch.zeros(100, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        classification.classification_bytes(vals, idx, table, out=small)

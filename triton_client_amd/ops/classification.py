@@ -63,14 +63,23 @@ def classification_bytes(values, indices, label_table=None, out=None):
     Returns ``(buffer uint8, size int)``.  ``out`` may be a preallocated uint8
     tensor (e.g. a view of a hipshm output region).
     """
+    buf, size = _launch_strings(values, indices, label_table, out)
+    n = int(size.item())
+    if n > buf.numel():
+        raise ValueError(f"classification payload needs {n} bytes but the destination holds {buf.numel()}")
+    return buf, n
+
+
+def _launch_strings(values, indices, label_table, out=None, size=None):
     import torch
 
     rows, k = values.shape
     entries = rows * k
-    cap = entries * (4 + 64 + ((label_table.max_len + 1) if label_table is not None else 0))
     if out is None:
+        cap = entries * (4 + 64 + ((label_table.max_len + 1) if label_table is not None else 0))
         out = torch.empty(cap, dtype=torch.uint8, device=values.device)
-    size = torch.zeros(1, dtype=torch.int64, device=values.device)
+    if size is None:
+        size = torch.zeros(1, dtype=torch.int64, device=values.device)
     rc = lib().tca_classify_strings_launch(
         values.contiguous().data_ptr(), indices.contiguous().data_ptr(), rows, k,
         label_table.data.data_ptr() if label_table is not None else None,
@@ -78,10 +87,43 @@ def classification_bytes(values, indices, label_table=None, out=None):
         label_table.count if label_table is not None else 0, out.data_ptr(), out.numel(), size.data_ptr(),
         torch.cuda.current_stream().cuda_stream)
     check(rc, "tca_classify_strings_launch")
-    n = int(size.item())
-    if n > out.numel():
-        raise ValueError(f"classification payload needs {n} bytes but the destination holds {out.numel()}")
-    return out, n
+    return out, size
+
+
+def classification_payload_async(logits, k, label_table=None):
+    """Enqueue top-k + string formatting + one device-to-host copy on the
+    current stream.  Returns ``(pinned uint8 tensor, shape)``; after the stream
+    (or an event recorded behind this call) completed, hand both to
+    :func:`finish_payload`.  Payload size and payload share the buffer, so
+    nothing needs a second round trip."""
+    import torch
+
+    vals, idx = topk(logits, k)
+    rows, kk = vals.shape
+    per = 4 + 64 + ((label_table.max_len + 1) if label_table is not None else 0)
+    buf = torch.empty(8 + rows * kk * per, dtype=torch.uint8, device=vals.device)
+    _launch_strings(vals, idx, label_table, buf[8:], buf[:8].view(torch.int64))
+    host = torch.empty(buf.shape, dtype=torch.uint8, pin_memory=True)
+    host.copy_(buf, non_blocking=True)
+    # the caching allocator may hand vals/idx/buf to a later request once they
+    # go out of scope; uses on the same stream stay ordered behind this copy
+    return host, ([rows, kk] if logits.dim() > 1 else [kk])
+
+
+def finish_payload(host, shape):
+    """``(bytes, shape)`` of a completed :func:`classification_payload_async`."""
+    arr = host.numpy()
+    n = int(arr[:8].view(np.int64)[0])
+    return arr[8: 8 + n].tobytes(), shape
+
+
+def classification_payload(logits, k, label_table=None):
+    """Synchronous form: the BYTES wire payload (host ``bytes``) and its shape."""
+    import torch
+
+    host, shape = classification_payload_async(logits, k, label_table)
+    torch.cuda.current_stream().synchronize()
+    return finish_payload(host, shape)
 
 
 def topk_strings(logits, k, labels=None):

@@ -253,8 +253,12 @@ class DynamicBatcher:
             for name, value in result.items():
                 k = needs_topk.get(name, 0)
                 if k:
-                    vals, idx = torch.topk(value, min(k, value.shape[-1]), dim=-1)
-                    out[name] = ("topk", vals.to("cpu", non_blocking=True), idx.to("cpu", non_blocking=True))
+                    from ..ops import classification
+
+                    if self.lm.label_table is None and self.model.labels:
+                        self.lm.label_table = classification.LabelTable(self.model.labels, value.device)
+                    host, shape = classification.classification_payload_async(value, k, self.lm.label_table)
+                    out[name] = ("packed", host, shape)
                 else:
                     host = torch.empty(value.shape, dtype=value.dtype, pin_memory=True)
                     host.copy_(value, non_blocking=True)
@@ -279,8 +283,11 @@ class DynamicBatcher:
                 try:
                     final = {}
                     for name, value in result.items():
-                        if isinstance(value, tuple) and value[0] == "topk":
-                            final[name] = self._format_topk(value[1].numpy(), value[2].numpy(), it)
+                        if isinstance(value, tuple) and value[0] == "packed":
+                            from ..ops.classification import finish_payload
+                            from .core import PackedBytes
+
+                            final[name] = PackedBytes(*finish_payload(value[1], value[2]))
                         elif hasattr(value, "is_cuda") and not value.is_cuda:
                             final[name] = value.numpy()
                         else:
@@ -298,21 +305,8 @@ class DynamicBatcher:
                     it.error = ServerError(f"internal error: {type(e).__name__}: {e}", 500)
                 it.done.set()
 
-    def _format_topk(self, vals, idx, it):
-        labels = self.model.labels
-        rows, k = vals.shape
-        out = np.empty((rows, k), dtype=np.object_)
-        for r in range(rows):
-            for c in range(k):
-                i = int(idx[r, c])
-                text = "%f:%d" % (float(vals[r, c]), i)
-                if labels is not None and i < len(labels):
-                    text += ":" + labels[i]
-                out[r, c] = text.encode("utf-8")
-        return out
-
     def _respond(self, it, final, requested, out_specs, dev_inputs):
-        from .core import InferResponse, OutputTensor
+        from .core import InferResponse, OutputTensor, PackedBytes
 
         resp = InferResponse(model_name=it.req.model_name, model_version=it.version, id=it.req.id)
         for ro in requested:
@@ -325,7 +319,7 @@ class DynamicBatcher:
                 resp.outputs.append(OutputTensor(ro.name, spec.datatype, list(value.shape), None, ro.shm))
                 continue
             datatype = "BYTES" if ro.class_count else spec.datatype
-            if not isinstance(value, np.ndarray):
+            if not isinstance(value, (np.ndarray, PackedBytes)):
                 value = value.detach().cpu().numpy()
             if ro.shm is not None:
                 self.core._write_shm(ro, datatype, value)

@@ -333,8 +333,29 @@ def _decode_json(datatype, shape, data, name):
     return np.array(flat, dtype=npdt).reshape(shape)
 
 
+class PackedBytes:
+    """A BYTES tensor that already is in wire form (``<u32 len><bytes>`` per
+    element), e.g. classification strings formatted by the GPU kernel.  Fronts
+    that need the elements (JSON output) unpack it on demand."""
+
+    __slots__ = ("blob", "shape")
+    dtype = np.dtype(np.object_)
+
+    def __init__(self, blob, shape):
+        self.blob = blob
+        self.shape = tuple(shape)
+
+    def unpack(self):
+        return deserialize_bytes_tensor(self.blob).reshape(self.shape)
+
+    def reshape(self, *shape):
+        return self.unpack().reshape(*shape)
+
+
 def encode_wire(datatype, arr):
     """ndarray -> wire bytes."""
+    if isinstance(arr, PackedBytes):
+        return arr.blob
     if datatype == "BYTES":
         packed = serialize_byte_tensor(arr)
         return packed.item() if packed.size else b""
@@ -367,6 +388,7 @@ class LoadedModel:
     def __init__(self, model, device_index=None):
         self.model = model
         self.stats = {v: ModelStats() for v in model.versions}
+        self.label_table = None  # class labels resident on the GPU, built on first classification request
         self.sequences = {}
         self.seq_lock = threading.Lock()
         self.exec_lock = threading.Lock()  # CPU models run serially per instance like a single instance group
@@ -827,7 +849,11 @@ class InferenceCore:
         if not isinstance(value, np.ndarray):
             from ..ops import classification
 
-            return classification.topk_strings(value, k, labels)
+            table = lm.label_table
+            if table is None and labels:
+                table = lm.label_table = classification.LabelTable(labels, value.device)
+            blob, shape = classification.classification_payload(value, k, table)
+            return PackedBytes(blob, shape)
         return format_classification(value, labels, k)
 
     def _write_shm(self, ro: RequestedOutput, datatype, value):
