@@ -1,0 +1,324 @@
+// Convolution building blocks for NHWC fp16 inference on gfx950 (CDNA4).
+//
+//   Conv1x1Kernel   a 1x1 convolution in NHWC IS a GEMM:
+//                       Y[m][n] = act( sum_k X[row(m)][k] * W[n][k] + bias[n] (+ R[m][n]) )
+//                   with m over the N*OH*OW output pixels, k over input and n
+//                   over output channels.  Both operands are K-contiguous, so
+//                   MFMA fragments are plain 16-byte reads.  Bias, the residual
+//                   add and ReLU run in the epilogue on the fp32 accumulator:
+//                   the activation is written to HBM exactly once instead of
+//                   being re-read and re-written by two or three elementwise
+//                   passes.  Stride-2 (down-sampling shortcut) only changes
+//                   row(m).
+//   BiasActKernel   the same epilogue as a stand-alone, 16-byte vectorised
+//                   in-place pass for convolutions a library computed (3x3,
+//                   7x7): one pass instead of bias-add, residual-add and ReLU
+//                   passes.
+//
+// GEMM structure: 256 threads = 4 wavefronts (2x2), block tile BM x BN, K step
+// 64, v_mfma_f32_16x16x32_f16.  The weight tile is the MFMA A operand and the
+// activation tile the B operand, i.e. the wave computes Y^T fragments: each
+// lane then owns 4 CONSECUTIVE output channels of one pixel, which packs into
+// one 8-byte LDS store for the epilogue transpose.  Tiles are staged
+// global -> registers -> LDS with the next tile's loads in flight during the
+// MFMAs (two LDS stages when K > 64).  LDS rows are 128 bytes; the 16-byte
+// chunk index is XOR-ed with (row>>1)&7, which makes every ds_read_b128 of a
+// fragment (16 rows x 4 chunks per wave instruction) bank-conflict free for
+// the instruction's four 16-lane groups.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half4 = __attribute__((ext_vector_type(4))) _Float16;
+using float4v = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kThreads = 256;
+constexpr int kBK = 64;  // halfs per K step = 128-byte LDS rows
+
+struct RowMap {  // output pixel index -> input pixel index
+  int identity;  // 1: row(m) = m
+  int ohw;       // OH*OW
+  int ow;        // OW
+  int in_hw;     // H*W of the input
+  int in_w;      // W of the input
+  int stride;
+};
+
+__device__ __forceinline__ long long InRow(const RowMap& map, int m) {
+  if (map.identity) return m;
+  const int img = m / map.ohw;
+  const int rem = m - img * map.ohw;
+  const int oh = rem / map.ow;
+  const int ow = rem - oh * map.ow;
+  return static_cast<long long>(img) * map.in_hw + static_cast<long long>(oh) * map.stride * map.in_w + ow * map.stride;
+}
+
+// 16-byte chunk position inside a 128-byte LDS row
+__device__ __forceinline__ int Swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(kThreads) void Conv1x1Kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
+                                                          const _Float16* __restrict__ bias,
+                                                          const _Float16* __restrict__ residual,
+                                                          _Float16* __restrict__ Y, int M, int N, int K, int relu,
+                                                          RowMap map, int tiles_n, int xcd_chunk) {
+  constexpr int kAVecs = BM * 8 / kThreads;  // 16-byte vectors per thread and stage (activation tile)
+  constexpr int kWVecs = BN * 8 / kThreads;  // (weight tile)
+  constexpr int kMI = BM / 32;               // 16-wide fragments per wave along m
+  constexpr int kNI = BN / 32;               // along n
+  constexpr int kStageHalfs = (BM + BN) * kBK;
+  constexpr int kCPitch = BN + 8;  // halfs; 16-byte aligned rows, spreads the transposed stores over banks
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+
+  // XCD-aware tile order: consecutive block ids land on different XCDs, so give
+  // each XCD a contiguous run of tiles (neighbouring n tiles share the X rows in L2)
+  int bid = blockIdx.x;
+  if (xcd_chunk > 0) bid = (bid & 7) * xcd_chunk + (bid >> 3);
+  const int tile_m = bid / tiles_n;
+  const int tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1;  // wave row (m)
+  const int wn = wave & 1;   // wave column (n)
+
+  // staging assignment: vector v -> (row v/8, chunk v%8)
+  const _Float16* a_src[kAVecs];
+  int a_dst[kAVecs];
+#pragma unroll
+  for (int i = 0; i < kAVecs; ++i) {
+    const int v = tid + i * kThreads;
+    const int row = v >> 3, chunk = v & 7;
+    const int m = m0 + row;
+    a_src[i] = (m < M) ? X + InRow(map, m) * K + chunk * 8 : nullptr;
+    a_dst[i] = row * kBK + Swz(row, chunk) * 8;
+  }
+  const _Float16* w_src[kWVecs];
+  int w_dst[kWVecs];
+#pragma unroll
+  for (int i = 0; i < kWVecs; ++i) {
+    const int v = tid + i * kThreads;
+    const int row = v >> 3, chunk = v & 7;
+    w_src[i] = W + static_cast<long long>(n0 + row) * K + chunk * 8;  // N % BN == 0 (host checked)
+    w_dst[i] = BM * kBK + row * kBK + Swz(row, chunk) * 8;
+  }
+
+  half8 a_reg[kAVecs], w_reg[kWVecs];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < kAVecs; ++i) {
+      if (a_src[i] != nullptr) a_reg[i] = *reinterpret_cast<const half8*>(a_src[i] + k0);
+      else a_reg[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < kWVecs; ++i) w_reg[i] = *reinterpret_cast<const half8*>(w_src[i] + k0);
+  };
+  auto store_tile = [&](int stage) {
+    _Float16* base = lds + stage * kStageHalfs;
+#pragma unroll
+    for (int i = 0; i < kAVecs; ++i) *reinterpret_cast<half8*>(base + a_dst[i]) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < kWVecs; ++i) *reinterpret_cast<half8*>(base + w_dst[i]) = w_reg[i];
+  };
+
+  float4v acc[kNI][kMI];
+#pragma unroll
+  for (int ni = 0; ni < kNI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < kMI; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  const int ktiles = K / kBK;
+  const int stages = ktiles > 1 ? 2 : 1;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int frag_row = lane & 15;
+  const int frag_chunk = lane >> 4;
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const bool more = kt + 1 < ktiles;
+    if (more) load_tile((kt + 1) * kBK);  // in flight while the MFMAs below run
+    const _Float16* xs = lds + (stages == 2 ? (kt & 1) : 0) * kStageHalfs;
+    const _Float16* ws = xs + BM * kBK;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8 xf[kMI], wf[kNI];
+#pragma unroll
+      for (int mi = 0; mi < kMI; ++mi) {
+        const int row = wm * (BM / 2) + mi * 16 + frag_row;
+        xf[mi] = *reinterpret_cast<const half8*>(xs + row * kBK + Swz(row, kk * 4 + frag_chunk) * 8);
+      }
+#pragma unroll
+      for (int ni = 0; ni < kNI; ++ni) {
+        const int row = wn * (BN / 2) + ni * 16 + frag_row;
+        wf[ni] = *reinterpret_cast<const half8*>(ws + row * kBK + Swz(row, kk * 4 + frag_chunk) * 8);
+      }
+#pragma unroll
+      for (int ni = 0; ni < kNI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < kMI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if (more) {
+      store_tile((kt + 1) & 1);  // the other stage: last read one iteration ago, behind a barrier
+      __syncthreads();
+    }
+  }
+  __syncthreads();  // every wave is done reading the operand stages: reuse them for the output tile
+
+  // accumulator (+bias, fp32) -> LDS as fp16 [BM][kCPitch]; D^T layout: lane holds
+  // pixel m = lane&15 and channels n = 4*(lane>>4) .. +3 of each fragment
+  _Float16* cs = lds;
+#pragma unroll
+  for (int ni = 0; ni < kNI; ++ni) {
+    const int n_local = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+      const half4 bv = *reinterpret_cast<const half4*>(bias + n0 + n_local);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(bv[r]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < kMI; ++mi) {
+      const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
+      half4 packed;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) packed[r] = static_cast<_Float16>(acc[ni][mi][r] + b[r]);
+      *reinterpret_cast<half4*>(cs + m_local * kCPitch + n_local) = packed;
+    }
+  }
+  __syncthreads();
+
+  // coalesced 16-byte epilogue: residual add, ReLU, store
+  constexpr int kRowVecs = BN / 8;
+  constexpr int kOutVecs = BM * kRowVecs / kThreads;
+#pragma unroll
+  for (int i = 0; i < kOutVecs; ++i) {
+    const int v = tid + i * kThreads;
+    const int row = v / kRowVecs;
+    const int cv = v - row * kRowVecs;
+    const int m = m0 + row;
+    if (m >= M) continue;
+    half8 val = *reinterpret_cast<const half8*>(cs + row * kCPitch + cv * 8);
+    const long long off = static_cast<long long>(m) * N + n0 + cv * 8;
+    if (residual != nullptr) {
+      const half8 res = *reinterpret_cast<const half8*>(residual + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) val[j] = static_cast<_Float16>(static_cast<float>(val[j]) + static_cast<float>(res[j]));
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) val[j] = val[j] > static_cast<_Float16>(0) ? val[j] : static_cast<_Float16>(0);
+    }
+    *reinterpret_cast<half8*>(Y + off) = val;
+  }
+}
+
+// y[m][c] = act(y[m][c] + bias[c] (+ residual[m][c])) in place, 8 halfs per thread.
+__global__ __launch_bounds__(kThreads) void BiasActKernel(_Float16* __restrict__ y, const _Float16* __restrict__ bias,
+                                                          const _Float16* __restrict__ residual, long long vecs,
+                                                          int channel_vecs, int relu) {
+  const long long stride = static_cast<long long>(gridDim.x) * kThreads;
+  for (long long v = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x; v < vecs; v += stride) {
+    half8 val = *reinterpret_cast<const half8*>(y + v * 8);
+    const int cv = static_cast<int>(v % channel_vecs);
+    const half8 b = *reinterpret_cast<const half8*>(bias + cv * 8);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = static_cast<float>(val[j]) + static_cast<float>(b[j]);
+    if (residual != nullptr) {
+      const half8 r = *reinterpret_cast<const half8*>(residual + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += static_cast<float>(r[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (relu && f[j] < 0.f) f[j] = 0.f;
+      val[j] = static_cast<_Float16>(f[j]);
+    }
+    *reinterpret_cast<half8*>(y + v * 8) = val;
+  }
+}
+
+template <int BM, int BN>
+int LaunchConv1x1(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
+                  int M, int N, int K, int relu, const RowMap& map, hipStream_t st) {
+  const int tiles_m = (M + BM - 1) / BM;
+  const int tiles_n = N / BN;
+  const int blocks = tiles_m * tiles_n;
+  const int xcd_chunk = (blocks % 8 == 0) ? blocks / 8 : 0;  // the remap must be a bijection
+  const int stages = (K / kBK) > 1 ? 2 : 1;
+  size_t lds_bytes = static_cast<size_t>(stages) * (BM + BN) * kBK * sizeof(_Float16);
+  const size_t c_bytes = static_cast<size_t>(BM) * (BN + 8) * sizeof(_Float16);
+  if (c_bytes > lds_bytes) lds_bytes = c_bytes;
+  hipLaunchKernelGGL((Conv1x1Kernel<BM, BN>), dim3(blocks), dim3(kThreads), lds_bytes, st, x, w, bias, residual, y, M,
+                     N, K, relu, map, tiles_n, xcd_chunk);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
+}
+
+}  // namespace
+
+extern "C" {
+
+// variant: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile.
+int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                       int in_h, int in_w, int stride, int cin, int cout, int relu, int variant, void* stream) {
+  if (!x || !w || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || stride <= 0) return -1;
+  if (cin % kBK != 0 || cout % 64 != 0) return -2;  // whole K steps, whole n tiles
+  const int oh = (in_h - 1) / stride + 1;
+  const int ow = (in_w - 1) / stride + 1;
+  const long long m_ll = static_cast<long long>(batch) * oh * ow;
+  if (m_ll > 0x7FFFFFFF) return -2;
+  const int M = static_cast<int>(m_ll);
+  RowMap map;
+  map.identity = stride == 1;
+  map.ohw = oh * ow;
+  map.ow = ow;
+  map.in_hw = in_h * in_w;
+  map.in_w = in_w;
+  map.stride = stride;
+  if (variant == 0) {
+    // fill the 256 CUs first, then prefer the bigger tile (more reuse per byte staged)
+    const long long b128 = (cout % 128 == 0) ? static_cast<long long>((M + 127) / 128) * (cout / 128) : 0;
+    const long long b64 = static_cast<long long>((M + 127) / 128) * (cout / 64);
+    variant = (b128 >= 512) ? 1 : (b64 >= 384 ? 2 : 3);
+  }
+  if (variant == 1 && cout % 128 != 0) return -2;
+  auto st = static_cast<hipStream_t>(stream);
+  auto xp = static_cast<const _Float16*>(x);
+  auto wp = static_cast<const _Float16*>(w);
+  auto bp = static_cast<const _Float16*>(bias);
+  auto rp = static_cast<const _Float16*>(residual);
+  auto yp = static_cast<_Float16*>(y);
+  switch (variant) {
+    case 1: return LaunchConv1x1<128, 128>(xp, wp, bp, rp, yp, M, cout, cin, relu, map, st);
+    case 2: return LaunchConv1x1<128, 64>(xp, wp, bp, rp, yp, M, cout, cin, relu, map, st);
+    case 3: return LaunchConv1x1<64, 64>(xp, wp, bp, rp, yp, M, cout, cin, relu, map, st);
+    default: return -3;
+  }
+}
+
+int tca_bias_act_launch(void* y, const void* bias, const void* residual, long long rows, int channels, int relu,
+                        void* stream) {
+  if (!y || !bias || rows <= 0 || channels <= 0) return -1;
+  if (channels % 8 != 0) return -2;
+  const long long vecs = rows * (channels / 8);
+  long long blocks = (vecs + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+  hipLaunchKernelGGL(BiasActKernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), static_cast<_Float16*>(y), static_cast<const _Float16*>(bias),
+                     static_cast<const _Float16*>(residual), vecs, channels / 8, relu);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
+}
+
+}  // extern "C"

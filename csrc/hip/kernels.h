@@ -66,4 +66,13 @@ int tca_topk_launch(const void* logits, int dtype, int rows, int cols, int k, fl
 int tca_classify_strings_launch(const float* values, const int* indices, int rows, int k, const uint8_t* labels,
                                 const uint32_t* label_offsets, int num_labels, uint8_t* out, uint64_t out_cap,
                                 uint64_t* out_size, void* stream);
+
+// NHWC fp16 convolution pieces.  1x1 convolution as an MFMA GEMM with bias /
+// residual / ReLU in its epilogue (x: [batch,in_h,in_w,cin], w: [cout,cin],
+// y: [batch,oh,ow,cout]; variant 0 = pick the block tile), and the same
+// epilogue as an in-place pass over a library convolution's output.
+int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                       int in_h, int in_w, int stride, int cin, int cout, int relu, int variant, void* stream);
+int tca_bias_act_launch(void* y, const void* bias, const void* residual, long long rows, int channels, int relu,
+                        void* stream);
 }

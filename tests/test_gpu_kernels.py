@@ -207,3 +207,72 @@ def test_classification_payload_many_entries(torch, rows, k, with_labels):
     small = torch.zeros(100, dtype=torch.uint8, device="cuda")
     with pytest.raises(ValueError):
         classification.classification_bytes(vals, idx, table, out=small)
+
+
+def _nhwc(t):
+    import torch as _torch
+
+    return t.contiguous(memory_format=_torch.channels_last)
+
+
+@pytest.mark.parametrize("variant", ["auto", "128x128", "128x64", "64x64"])
+@pytest.mark.parametrize("shape", [
+    # batch, H, W, Cin, Cout, stride, residual, relu
+    (2, 56, 56, 64, 256, 1, True, True),
+    (3, 28, 28, 512, 128, 1, False, True),
+    (2, 56, 56, 256, 512, 2, False, False),
+    (5, 7, 7, 2048, 512, 1, False, True),   # M = 245: ragged last tile
+    (1, 14, 14, 1024, 2048, 2, True, True),
+])
+def test_conv1x1_mfma_matches_fp32_reference(torch, shape, variant):
+    from triton_client_amd.ops import conv
+
+    b, h, w, cin, cout, stride, with_res, relu = shape
+    gen = torch.Generator(device="cuda").manual_seed(cin + cout + h)
+    x = _nhwc(torch.randn(b, cin, h, w, device="cuda", generator=gen).half())
+    wt = (torch.randn(cout, cin, device="cuda", generator=gen) / cin ** 0.5).half()
+    bias = torch.randn(cout, device="cuda", generator=gen).half()
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = _nhwc(torch.randn(b, cout, oh, ow, device="cuda", generator=gen).half()) if with_res else None
+    got = conv.conv1x1(x, wt, bias, res, relu=relu, stride=stride, variant=variant)
+    ref = torch.nn.functional.conv2d(x.float(), wt.float().reshape(cout, cin, 1, 1), bias.float(), stride=stride)
+    if with_res:
+        ref = ref + res.float()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(got.float(), ref, rtol=4e-3, atol=4e-3)
+
+
+def test_conv1x1_exact_integer_operand_maps(torch):
+    """Small integers make every product and sum exact in fp16/fp32, so a wrong
+    MFMA lane map (row/column swap, k permutation) cannot hide in rounding; the
+    weight matrix is asymmetric on purpose."""
+    from triton_client_amd.ops import conv
+
+    b, h, w, cin, cout = 1, 12, 12, 64, 128
+    x = _nhwc(torch.randint(-3, 4, (b, cin, h, w), device="cuda").half())
+    wt = torch.randint(-2, 3, (cout, cin), device="cuda").half()
+    wt[5, 7] = 9.0
+    bias = torch.arange(cout, device="cuda").half()
+    for variant in ("128x128", "128x64", "64x64"):
+        got = conv.conv1x1(x, wt, bias, None, relu=False, variant=variant)
+        ref = torch.nn.functional.conv2d(x.float(), wt.float().reshape(cout, cin, 1, 1), bias.float())
+        assert torch.equal(got.float(), ref), variant
+
+
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (True, False)])
+def test_bias_act_inplace(torch, with_res, relu):
+    from triton_client_amd.ops import conv
+
+    y = _nhwc(torch.randn(4, 192, 17, 13, device="cuda").half())
+    bias = torch.randn(192, device="cuda").half()
+    res = _nhwc(torch.randn(4, 192, 17, 13, device="cuda").half()) if with_res else None
+    ref = y.float() + bias.float().reshape(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.float()
+    if relu:
+        ref = ref.clamp_min(0)
+    out = conv.bias_act_(y, bias, res, relu=relu)
+    assert out is y
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)

@@ -15,7 +15,8 @@ def main():
     ap.add_argument("--batches", default="8,16,32,64,128")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--benchmark", type=int, default=1)
+    ap.add_argument("--benchmark", type=int, default=0)
+    ap.add_argument("--no-fused", action="store_true", help="plain library forward instead of the fused kernels")
     args = ap.parse_args()
     import torch
 
@@ -26,7 +27,8 @@ def main():
     model.load(0)
     torch.backends.cudnn.benchmark = bool(args.benchmark)
     model.use_graphs = not args.no_graph
-    print(f"load {time.time() - t0:.1f}s graphs={model.use_graphs} benchmark={args.benchmark}", flush=True)
+    model.fused = not args.no_fused
+    print(f"load {time.time() - t0:.1f}s graphs={model.use_graphs} fused={model.fused} benchmark={args.benchmark}", flush=True)
     for b in [int(x) for x in args.batches.split(",")]:
         x = torch.randn(b, 3, 224, 224, device="cuda", dtype=torch.float16)
         out = torch.empty(b, 1000, device="cuda", dtype=torch.float32)

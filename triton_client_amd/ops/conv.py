@@ -1,0 +1,89 @@
+"""NHWC fp16 convolution pieces with fused epilogues (inference).
+
+``conv1x1``   1x1 convolution as a hand-written MFMA GEMM whose epilogue adds
+              the bias, optionally the residual branch, applies ReLU and writes
+              the activation once (kernel: ``csrc/hip/conv_gemm.hip``).
+``bias_act_`` the same epilogue as ONE in-place pass for convolutions computed
+              by a library (3x3 / 7x7): replaces the separate bias-add,
+              residual-add and ReLU passes of an eager forward.
+
+Tensors are torch CUDA tensors in channels-last memory format, i.e. logical
+``[N, C, H, W]`` with strides of a ``[N, H, W, C]`` array.  The reference has no
+model code (its models run in the server it talks to, e.g.
+``src/python/examples/image_client.py:59-150`` only inspects metadata); this is
+the serving side of that contract on MI355X.
+"""
+
+from __future__ import annotations
+
+from ._device import check, lib
+
+VARIANTS = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3}
+
+
+def _stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _is_nhwc(t):
+    import torch
+
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0, out=None):
+    """``act(conv1x1(x, weight) + bias (+ residual))``.
+
+    x        fp16 ``[N, Cin, H, W]`` channels-last
+    weight   fp16 ``[Cout, Cin]`` (or ``[Cout, Cin, 1, 1]``), contiguous
+    bias     fp16 ``[Cout]`` or None
+    residual fp16 ``[N, Cout, OH, OW]`` channels-last or None
+    Cin must be a multiple of 64 and Cout of 64 (128 for the 128x128 tile).
+    """
+    import torch
+
+    if x.dtype != torch.float16 or weight.dtype != torch.float16:
+        raise TypeError("conv1x1 takes fp16 tensors")
+    if not _is_nhwc(x):
+        raise ValueError("x must be a channels-last [N, C, H, W] tensor")
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    if weight.numel() != cout * cin or not weight.is_contiguous():
+        raise ValueError(f"weight must be a contiguous [{cout}, {cin}] matrix")
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    if out is None:
+        out = torch.empty((n, cout, oh, ow), dtype=torch.float16, device=x.device,
+                          memory_format=torch.channels_last)
+    elif tuple(out.shape) != (n, cout, oh, ow) or not _is_nhwc(out):
+        raise ValueError("out must be a channels-last tensor of the output shape")
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not _is_nhwc(residual)
+                                 or residual.dtype != torch.float16):
+        raise ValueError("residual must match the output (fp16, channels-last)")
+    if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
+        raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
+    code = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    rc = lib().tca_conv1x1_launch(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                  residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w,
+                                  int(stride), cin, cout, 1 if relu else 0, code, _stream())
+    check(rc, "tca_conv1x1_launch")
+    return out
+
+
+def bias_act_(y, bias, residual=None, relu=False):
+    """In place ``y = act(y + bias (+ residual))`` on a channels-last fp16 tensor."""
+    import torch
+
+    if y.dtype != torch.float16 or not _is_nhwc(y):
+        raise ValueError("y must be a channels-last fp16 [N, C, H, W] tensor")
+    n, c, h, w = y.shape
+    if bias.numel() != c or bias.dtype != torch.float16 or not bias.is_contiguous():
+        raise ValueError("bias must be a contiguous fp16 vector of C elements")
+    if residual is not None and (tuple(residual.shape) != tuple(y.shape) or not _is_nhwc(residual)
+                                 or residual.dtype != torch.float16):
+        raise ValueError("residual must match y (fp16, channels-last)")
+    rc = lib().tca_bias_act_launch(y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                   n * h * w, c, 1 if relu else 0, _stream())
+    check(rc, "tca_bias_act_launch")
+    return y
