@@ -1,6 +1,6 @@
 // Convolution building blocks for NHWC fp16 inference on gfx950 (CDNA4).
 //
-//   Conv1x1Kernel   a 1x1 convolution in NHWC IS a GEMM:
+//   ConvGemmKernel  a 1x1 convolution in NHWC IS a GEMM:
 //                       Y[m][n] = act( sum_k X[row(m)][k] * W[n][k] + bias[n] (+ R[m][n]) )
 //                   with m over the N*OH*OW output pixels, k over input and n
 //                   over output channels.  Both operands are K-contiguous, so
@@ -10,6 +10,12 @@
 //                   being re-read and re-written by two or three elementwise
 //                   passes.  Stride-2 (down-sampling shortcut) only changes
 //                   row(m).
+//                   With kSpatial the same kernel is an implicit GEMM for RxR
+//                   convolutions (3x3): K runs over (kh, kw, cin) - exactly the
+//                   memory order of a channels-last weight - and every K step
+//                   of 64 channels belongs to ONE tap, so staging the
+//                   activation tile only shifts the source pixel per step and
+//                   zero-fills rows whose tap falls into the padding.
 //   BiasActKernel   the same epilogue as a stand-alone, 16-byte vectorised
 //                   in-place pass for convolutions a library computed (3x3,
 //                   7x7): one pass instead of bias-add, residual-add and ReLU
@@ -41,13 +47,16 @@ using float4v = __attribute__((ext_vector_type(4))) float;
 constexpr int kThreads = 256;
 constexpr int kBK = 64;  // halfs per K step = 128-byte LDS rows
 
-struct RowMap {  // output pixel index -> input pixel index
-  int identity;  // 1: row(m) = m
+struct RowMap {  // output pixel index -> input pixel(s)
+  int identity;  // 1: 1x1 stride 1, row(m) = m
   int ohw;       // OH*OW
   int ow;        // OW
-  int in_hw;     // H*W of the input
-  int in_w;      // W of the input
+  int in_h;
+  int in_w;
   int stride;
+  int pad;
+  int ksize;     // R = S
+  int cin;
 };
 
 __device__ __forceinline__ long long InRow(const RowMap& map, int m) {
@@ -56,14 +65,15 @@ __device__ __forceinline__ long long InRow(const RowMap& map, int m) {
   const int rem = m - img * map.ohw;
   const int oh = rem / map.ow;
   const int ow = rem - oh * map.ow;
-  return static_cast<long long>(img) * map.in_hw + static_cast<long long>(oh) * map.stride * map.in_w + ow * map.stride;
+  return static_cast<long long>(img) * map.in_h * map.in_w + static_cast<long long>(oh) * map.stride * map.in_w +
+         ow * map.stride;
 }
 
 // 16-byte chunk position inside a 128-byte LDS row
 __device__ __forceinline__ int Swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(kThreads) void Conv1x1Kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
+template <int BM, int BN, bool kSpatial>
+__global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias,
                                                           const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ Y, int M, int N, int K, int relu,
@@ -92,16 +102,29 @@ __global__ __launch_bounds__(kThreads) void Conv1x1Kernel(const _Float16* __rest
   const int wn = wave & 1;   // wave column (n)
 
   // staging assignment: vector v -> (row v/8, chunk v%8)
-  const _Float16* a_src[kAVecs];
+  const _Float16* a_src[kAVecs];  // 1x1: fixed row pointer; spatial: image base (+ chunk)
   int a_dst[kAVecs];
+  int a_ih0[kAVecs], a_iw0[kAVecs];  // spatial only: top-left input coordinate of the output pixel
 #pragma unroll
   for (int i = 0; i < kAVecs; ++i) {
     const int v = tid + i * kThreads;
     const int row = v >> 3, chunk = v & 7;
     const int m = m0 + row;
-    a_src[i] = (m < M) ? X + InRow(map, m) * K + chunk * 8 : nullptr;
     a_dst[i] = row * kBK + Swz(row, chunk) * 8;
+    if constexpr (kSpatial) {
+      const int img = m / map.ohw;
+      const int rem = m - img * map.ohw;
+      const int oh = rem / map.ow;
+      const int ow = rem - oh * map.ow;
+      a_src[i] = (m < M) ? X + static_cast<long long>(img) * map.in_h * map.in_w * map.cin + chunk * 8 : nullptr;
+      a_ih0[i] = oh * map.stride - map.pad;
+      a_iw0[i] = ow * map.stride - map.pad;
+    } else {
+      a_src[i] = (m < M) ? X + InRow(map, m) * K + chunk * 8 : nullptr;
+      a_ih0[i] = a_iw0[i] = 0;
+    }
   }
+  const int ctiles = kSpatial ? map.cin / kBK : 1;  // K steps per tap
   const _Float16* w_src[kWVecs];
   int w_dst[kWVecs];
 #pragma unroll
@@ -113,11 +136,27 @@ __global__ __launch_bounds__(kThreads) void Conv1x1Kernel(const _Float16* __rest
   }
 
   half8 a_reg[kAVecs], w_reg[kWVecs];
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * kBK;
+    if constexpr (kSpatial) {
+      const int tap = kt / ctiles;  // wave-uniform
+      const int c0 = (kt - tap * ctiles) * kBK;
+      const int kh = tap / map.ksize;
+      const int kw = tap - kh * map.ksize;
 #pragma unroll
-    for (int i = 0; i < kAVecs; ++i) {
-      if (a_src[i] != nullptr) a_reg[i] = *reinterpret_cast<const half8*>(a_src[i] + k0);
-      else a_reg[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < kAVecs; ++i) {
+        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+        const bool ok = a_src[i] != nullptr && static_cast<unsigned>(ih) < static_cast<unsigned>(map.in_h) &&
+                        static_cast<unsigned>(iw) < static_cast<unsigned>(map.in_w);
+        if (ok) a_reg[i] = *reinterpret_cast<const half8*>(a_src[i] + (static_cast<long long>(ih) * map.in_w + iw) * map.cin + c0);
+        else a_reg[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kAVecs; ++i) {
+        if (a_src[i] != nullptr) a_reg[i] = *reinterpret_cast<const half8*>(a_src[i] + k0);
+        else a_reg[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
     }
 #pragma unroll
     for (int i = 0; i < kWVecs; ++i) w_reg[i] = *reinterpret_cast<const half8*>(w_src[i] + k0);
@@ -145,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void Conv1x1Kernel(const _Float16* __rest
   const int frag_chunk = lane >> 4;
   for (int kt = 0; kt < ktiles; ++kt) {
     const bool more = kt + 1 < ktiles;
-    if (more) load_tile((kt + 1) * kBK);  // in flight while the MFMAs below run
+    if (more) load_tile(kt + 1);  // in flight while the MFMAs below run
     const _Float16* xs = lds + (stages == 2 ? (kt & 1) : 0) * kStageHalfs;
     const _Float16* ws = xs + BM * kBK;
 #pragma unroll
@@ -248,8 +287,8 @@ __global__ __launch_bounds__(kThreads) void BiasActKernel(_Float16* __restrict__
   }
 }
 
-template <int BM, int BN>
-int LaunchConv1x1(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
+template <int BM, int BN, bool kSpatial>
+int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = N / BN;
@@ -259,7 +298,7 @@ int LaunchConv1x1(const _Float16* x, const _Float16* w, const _Float16* bias, co
   size_t lds_bytes = static_cast<size_t>(stages) * (BM + BN) * kBK * sizeof(_Float16);
   const size_t c_bytes = static_cast<size_t>(BM) * (BN + 8) * sizeof(_Float16);
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
-  hipLaunchKernelGGL((Conv1x1Kernel<BM, BN>), dim3(blocks), dim3(kThreads), lds_bytes, st, x, w, bias, residual, y, M,
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kSpatial>), dim3(blocks), dim3(kThreads), lds_bytes, st, x, w, bias, residual, y, M,
                      N, K, relu, map, tiles_n, xcd_chunk);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
@@ -269,28 +308,39 @@ int LaunchConv1x1(const _Float16* x, const _Float16* w, const _Float16* bias, co
 
 extern "C" {
 
+// x: [batch,in_h,in_w,cin] fp16, w: [cout][ksize][ksize][cin] fp16 (the memory of
+// a channels-last [cout,cin,ksize,ksize] weight), y: [batch,oh,ow,cout].
 // variant: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile.
-int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
-                       int in_h, int in_w, int stride, int cin, int cout, int relu, int variant, void* stream) {
-  if (!x || !w || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || stride <= 0) return -1;
-  if (cin % kBK != 0 || cout % 64 != 0) return -2;  // whole K steps, whole n tiles
-  const int oh = (in_h - 1) / stride + 1;
-  const int ow = (in_w - 1) / stride + 1;
+int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                         int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu, int variant,
+                         void* stream) {
+  if (!x || !w || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || stride <= 0 || ksize <= 0 || pad < 0) return -1;
+  if (cin % kBK != 0 || cout % 64 != 0) return -2;  // whole K steps inside one tap, whole n tiles
+  const int oh = (in_h + 2 * pad - ksize) / stride + 1;
+  const int ow = (in_w + 2 * pad - ksize) / stride + 1;
+  if (oh <= 0 || ow <= 0) return -2;
   const long long m_ll = static_cast<long long>(batch) * oh * ow;
-  if (m_ll > 0x7FFFFFFF) return -2;
+  const long long k_ll = static_cast<long long>(ksize) * ksize * cin;
+  if (m_ll > 0x7FFFFFFF || k_ll > 0x7FFFFFFF) return -2;
   const int M = static_cast<int>(m_ll);
+  const int K = static_cast<int>(k_ll);
+  const bool spatial = ksize != 1 || pad != 0;
   RowMap map;
-  map.identity = stride == 1;
+  map.identity = !spatial && stride == 1;
   map.ohw = oh * ow;
   map.ow = ow;
-  map.in_hw = in_h * in_w;
+  map.in_h = in_h;
   map.in_w = in_w;
   map.stride = stride;
+  map.pad = pad;
+  map.ksize = ksize;
+  map.cin = cin;
   if (variant == 0) {
-    // fill the 256 CUs first, then prefer the bigger tile (more reuse per byte staged)
-    const long long b128 = (cout % 128 == 0) ? static_cast<long long>((M + 127) / 128) * (cout / 128) : 0;
-    const long long b64 = static_cast<long long>((M + 127) / 128) * (cout / 64);
-    variant = (b128 >= 512) ? 1 : (b64 >= 384 ? 2 : 3);
+    // enough blocks to fill 256 CUs several times over first, then the bigger
+    // tile (more reuse per staged byte); thresholds from per-layer timings
+    const long long blocks64 = static_cast<long long>((M + 63) / 64) * (cout / 64);
+    const long long blocks128x64 = static_cast<long long>((M + 127) / 128) * (cout / 64);
+    variant = blocks64 <= 2048 ? 3 : ((blocks128x64 <= 8192 || cout % 128 != 0) ? 2 : 1);
   }
   if (variant == 1 && cout % 128 != 0) return -2;
   auto st = static_cast<hipStream_t>(stream);
@@ -299,12 +349,26 @@ int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const voi
   auto bp = static_cast<const _Float16*>(bias);
   auto rp = static_cast<const _Float16*>(residual);
   auto yp = static_cast<_Float16*>(y);
+  if (spatial) {
+    switch (variant) {
+      case 1: return LaunchConvGemm<128, 128, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
+      case 2: return LaunchConvGemm<128, 64, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
+      case 3: return LaunchConvGemm<64, 64, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
+      default: return -3;
+    }
+  }
   switch (variant) {
-    case 1: return LaunchConv1x1<128, 128>(xp, wp, bp, rp, yp, M, cout, cin, relu, map, st);
-    case 2: return LaunchConv1x1<128, 64>(xp, wp, bp, rp, yp, M, cout, cin, relu, map, st);
-    case 3: return LaunchConv1x1<64, 64>(xp, wp, bp, rp, yp, M, cout, cin, relu, map, st);
+    case 1: return LaunchConvGemm<128, 128, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
+    case 2: return LaunchConvGemm<128, 64, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
+    case 3: return LaunchConvGemm<64, 64, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
     default: return -3;
   }
+}
+
+int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                       int in_h, int in_w, int stride, int cin, int cout, int relu, int variant, void* stream) {
+  return tca_conv_gemm_launch(x, w, bias, residual, y, batch, in_h, in_w, 1, stride, 0, cin, cout, relu, variant,
+                              stream);
 }
 
 int tca_bias_act_launch(void* y, const void* bias, const void* residual, long long rows, int channels, int relu,

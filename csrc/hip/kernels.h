@@ -73,6 +73,9 @@ int tca_classify_strings_launch(const float* values, const int* indices, int row
 // epilogue as an in-place pass over a library convolution's output.
 int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                        int in_h, int in_w, int stride, int cin, int cout, int relu, int variant, void* stream);
+int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                         int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu, int variant,
+                         void* stream);
 int tca_bias_act_launch(void* y, const void* bias, const void* residual, long long rows, int channels, int relu,
                         void* stream);
 }

@@ -1,0 +1,121 @@
+// gRPC-over-HTTP/2 channel for the native client: one TCP connection, one
+// reactor thread (epoll) that owns the HTTP/2 state machine, any number of
+// concurrent calls (unary and bidirectional streaming) multiplexed on it.
+//
+// The reference rides on grpc++ (`src/c++/library/grpc_client.cc:80-152`:
+// channel + stub cache); this toolchain has no grpc++, so the transport is
+// implemented here on tca/h2.h.  Calls are started from any thread; events are
+// delivered on the reactor thread.
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+
+#include "tca/common.h"
+#include "tca/error.h"
+#include "tca/h2.h"
+
+namespace tca {
+namespace client {
+
+// gRPC status codes used by this library.
+enum GrpcCode : int {
+  kGrpcOk = 0, kGrpcCancelled = 1, kGrpcUnknown = 2, kGrpcInvalidArgument = 3, kGrpcDeadlineExceeded = 4,
+  kGrpcNotFound = 5, kGrpcResourceExhausted = 8, kGrpcUnimplemented = 12, kGrpcInternal = 13, kGrpcUnavailable = 14,
+};
+
+struct KeepAliveOptions {
+  // Parity with the reference's struct (`grpc_client.h:77-97`).  An HTTP/2 PING
+  // is sent after `keepalive_time_ms` without traffic; the connection is
+  // dropped when the ack does not arrive within `keepalive_timeout_ms`.
+  int keepalive_time_ms = INT32_MAX;
+  int keepalive_timeout_ms = 20000;
+  bool keepalive_permit_without_calls = false;
+  int http2_max_pings_without_data = 2;
+};
+
+class GrpcChannel {
+ public:
+  struct CallEvents {
+    // One complete response message (without the 5-byte gRPC prefix).
+    std::function<void(std::string&& message)> on_message;
+    // Exactly once per call: gRPC status code and message.
+    std::function<void(int status, const std::string& message)> on_done;
+  };
+
+  static Error Create(std::shared_ptr<GrpcChannel>* channel, const std::string& url, bool verbose,
+                      const KeepAliveOptions& keepalive = KeepAliveOptions());
+  ~GrpcChannel();
+
+  // Starts a call on "/inference.GRPCInferenceService/<method>".  Never fails
+  // synchronously: connection problems surface through on_done.
+  uint64_t StartCall(const std::string& method, const Headers& metadata, uint64_t timeout_us, CallEvents events);
+  // Sends one request message; `last` half-closes the call.
+  void SendMessage(uint64_t call, std::string&& serialized, bool last);
+  void CloseSend(uint64_t call);
+  void Cancel(uint64_t call);
+
+  // Bytes accepted by SendMessage that have not reached the socket yet.
+  size_t PendingBytes() const { return pending_bytes_.load(); }
+  const std::string& Url() const { return url_; }
+
+ private:
+  GrpcChannel(std::string url, std::string host, int port, bool verbose, const KeepAliveOptions& keepalive);
+  struct Call {
+    uint32_t stream = 0;
+    CallEvents events;
+    std::string method;
+    Headers metadata;
+    uint64_t deadline_ns = 0;
+    uint64_t timeout_us = 0;
+    std::string rbuf;  // partial gRPC message
+    bool got_status = false;
+    int http_status = 0;
+    int grpc_status = -1;
+    std::string grpc_message;
+    bool send_closed = false;
+    std::deque<std::pair<std::string, bool>> unsent;  // queued before the stream opened
+  };
+  void Loop();
+  void Post(std::function<void()> fn);
+  bool EnsureConnected(std::string* why);
+  void Disconnect(const std::string& why);
+  void OpenCallStream(uint64_t id, Call* call);
+  void Finish(uint64_t id, int status, std::string message);  // by value: callers pass fields of the call being erased
+  void OnHeaders(uint32_t stream, h2::HeaderList&& headers, bool end_stream);
+  void OnData(uint32_t stream, const uint8_t* data, size_t len, bool end_stream);
+  void WriteSocket();
+  bool ReadSocket();
+
+  const std::string url_;
+  const std::string host_;
+  const int port_;
+  const bool verbose_;
+  const KeepAliveOptions keepalive_;
+
+  int fd_ = -1;
+  int epfd_ = -1;
+  int wake_fd_ = -1;
+  std::unique_ptr<h2::Connection> conn_;
+  std::map<uint64_t, Call> calls_;
+  std::map<uint32_t, uint64_t> by_stream_;
+  uint64_t last_activity_ns_ = 0;
+  uint64_t ping_sent_ns_ = 0;
+
+  std::thread thread_;
+  std::atomic<bool> stop_{false};
+  std::atomic<uint64_t> next_call_{1};
+  std::atomic<size_t> pending_bytes_{0};
+  std::mutex mu_;
+  std::deque<std::function<void()>> commands_;
+};
+
+}  // namespace client
+}  // namespace tca

@@ -36,6 +36,14 @@ def test_cc_client_suite(built, server):
     assert "0 failed" in out and "AsyncInferMulti" in out
 
 
+def test_grpc_unit_and_client_suite(built, server):
+    """HPACK / HTTP-2 / protobuf unit cases plus the gRPC client suite against
+    the in-repo server (a grpcio server: interoperability with the stock gRPC
+    implementation)."""
+    out = _run([os.path.join(built, "grpc_client_test"), "-u", server.grpc_url])
+    assert "0 failed" in out and "skipped" not in out and "GrpcDecoupledRepeat" in out
+
+
 def test_cc_timeout_and_leak_tools(built, server):
     assert "timeouts reported" in _run([os.path.join(built, "client_timeout_test"), "-u", server.http_url, "-t",
                                         "100000"])

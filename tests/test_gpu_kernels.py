@@ -276,3 +276,40 @@ def test_bias_act_inplace(torch, with_res, relu):
     out = conv.bias_act_(y, bias, res, relu=relu)
     assert out is y
     torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("variant", ["auto", "128x64", "64x64"])
+@pytest.mark.parametrize("shape", [
+    # batch, H, W, Cin, Cout, stride, relu
+    (2, 56, 56, 64, 64, 1, True),
+    (3, 56, 56, 128, 128, 2, True),
+    (2, 14, 14, 256, 256, 1, False),
+    (5, 7, 7, 512, 512, 1, True),      # M = 245, every border pixel pads
+    (1, 15, 13, 64, 128, 2, True),     # odd sizes
+])
+def test_conv3x3_implicit_gemm_matches_fp32_reference(torch, shape, variant):
+    from triton_client_amd.ops import conv
+
+    b, h, w, cin, cout, stride, relu = shape
+    gen = torch.Generator(device="cuda").manual_seed(cin * 3 + cout + h)
+    x = _nhwc(torch.randn(b, cin, h, w, device="cuda", generator=gen).half())
+    wt = _nhwc((torch.randn(cout, cin, 3, 3, device="cuda", generator=gen) / (9 * cin) ** 0.5).half())
+    bias = torch.randn(cout, device="cuda", generator=gen).half()
+    got = conv.conv2d(x, wt, bias, None, relu=relu, stride=stride, padding=1, variant=variant)
+    ref = torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=stride, padding=1)
+    if relu:
+        ref = ref.clamp_min(0)
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got.float(), ref, rtol=4e-3, atol=4e-3)
+
+
+def test_conv3x3_exact_integer_taps(torch):
+    """Integer data: a wrong tap order or padding rule changes exact sums."""
+    from triton_client_amd.ops import conv
+
+    x = _nhwc(torch.randint(-2, 3, (2, 64, 9, 11), device="cuda").half())
+    wt = _nhwc(torch.randint(-1, 2, (64, 64, 3, 3), device="cuda").half())
+    wt[3, 5, 0, 2] = 4.0  # asymmetric in (kh, kw)
+    got = conv.conv2d(x, wt, None, None, relu=False, stride=1, padding=1, variant="64x64")
+    ref = torch.nn.functional.conv2d(x.float(), wt.float(), None, stride=1, padding=1)
+    assert torch.equal(got.float(), ref)

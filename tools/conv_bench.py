@@ -21,6 +21,11 @@ LAYERS = [
 ]
 
 
+# (H, W, C, stride) of every distinct 3x3 convolution (Cin == Cout)
+LAYERS_3X3 = [(56, 56, 64, 1), (56, 56, 128, 2), (28, 28, 128, 1), (28, 28, 256, 2), (14, 14, 256, 1),
+              (14, 14, 512, 2), (7, 7, 512, 1)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="8,32,128")
@@ -99,6 +104,30 @@ def main():
             mf = min(times[k] for k in ("128x128", "128x64", "64x64") if times[k] == times[k])
             t["mfma_best"] += mf
             t["best"] += min(mf, times["lib+ep"])
+        for (h, w, c, stride) in LAYERS_3X3:
+            x = torch.randn(b, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+            wt = (torch.randn(c, c, 3, 3, device=dev) / (9 * c) ** 0.5).half().contiguous(
+                memory_format=torch.channels_last)
+            bias = torch.randn(c, device=dev).half()
+
+            def eager3():
+                return torch.relu_(F.conv2d(x, wt, bias, stride=stride, padding=1))
+
+            def lib_ep3():
+                return conv.bias_act_(F.conv2d(x, wt, None, stride=stride, padding=1), bias, None, True)
+
+            times = {"eager": graph_time(eager3), "lib+ep": graph_time(lib_ep3)}
+            for variant in ("128x128", "128x64", "64x64"):
+                if variant == "128x128" and c % 128:
+                    times[variant] = float("nan")
+                    continue
+                times[variant] = graph_time(
+                    lambda v=variant: conv.conv2d(x, wt, bias, None, relu=True, stride=stride, padding=1, variant=v))
+            best = min((k for k in times if times[k] == times[k]), key=lambda k: times[k])
+            name = f"3x3 {h}x{w} {c}->{c} s{stride}"
+            print(f"{b:5d} {name:>26} " + " ".join(f"{times[k]:8.2f}" for k in
+                                                  ("eager", "lib+ep", "128x128", "128x64", "64x64")) + f"  {best}",
+                  flush=True)
     for b, t in totals.items():
         print(f"batch {b}: sum over distinct layers (us): " + ", ".join(f"{k}={v:.1f}" for k, v in t.items()), flush=True)
 

@@ -259,21 +259,37 @@ class ResNet50(Model):
     def _features_fused(self, x):
         """ResNet-50 trunk with every bias / residual / ReLU fused: 1x1
         convolutions run on the MFMA GEMM kernel with the epilogue inside,
-        spatial convolutions on the library kernel followed by ONE in-place
-        epilogue pass.  53 + 17 kernels instead of 53 + 118."""
+        3x3 convolutions on the same kernel as an implicit GEMM where the
+        layer has enough output tiles to fill the chip, otherwise on the library
+        kernel followed by ONE in-place epilogue pass."""
         torch = self._torch
         F = torch.nn.functional
         from ..ops import conv
 
+        def pointwise(t, layer, residual, relu):
+            w2, bias, stride = layer
+            cout, cin = w2.shape
+            pixels = t.shape[0] * ((t.shape[2] - 1) // stride + 1) * ((t.shape[3] - 1) // stride + 1)
+            if conv.gemm_pays(pixels, cout, cin):
+                return conv.conv1x1(t, w2, bias, residual, relu=relu, stride=stride)
+            return conv.bias_act_(F.conv2d(t, w2.reshape(cout, cin, 1, 1), None, stride=stride), bias, residual, relu)
+
+        def spatial(t, layer):
+            w4, bias, stride, pad = layer
+            cout, cin, r, _ = w4.shape
+            pixels = t.shape[0] * ((t.shape[2] + 2 * pad - r) // stride + 1) * ((t.shape[3] + 2 * pad - r) // stride + 1)
+            if cin % 64 == 0 and conv.gemm_pays(pixels, cout, cin * r * r):
+                return conv.conv2d(t, w4, bias, None, relu=True, stride=stride, padding=pad)
+            return conv.bias_act_(F.conv2d(t, w4, None, stride=stride, padding=pad), bias, None, True)
+
         stem, blocks = self._plan
-        w, b, stride, pad = stem
-        y = conv.bias_act_(F.conv2d(x, w, None, stride=stride, padding=pad), b, None, True)
+        y = spatial(x, stem)  # Cin = 3: library kernel + fused epilogue
         y = F.max_pool2d(y, 3, stride=2, padding=1)
         for a, mid, c, down in blocks:
-            identity = y if down is None else conv.conv1x1(y, down[0], down[1], None, relu=False, stride=down[2])
-            t = conv.conv1x1(y, a[0], a[1], None, relu=True)
-            t = conv.bias_act_(F.conv2d(t, mid[0], None, stride=mid[2], padding=mid[3]), mid[1], None, True)
-            y = conv.conv1x1(t, c[0], c[1], identity, relu=True)
+            identity = y if down is None else pointwise(y, down, None, False)
+            t = pointwise(y, a, None, True)
+            t = spatial(t, mid)
+            y = pointwise(t, c, identity, True)
         return y.mean(dim=(2, 3))
 
     def _forward_into(self, x, out):

@@ -21,6 +21,17 @@ from ._device import check, lib
 VARIANTS = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3}
 
 
+def gemm_pays(pixels, cout, k_total):
+    """Whether the MFMA GEMM kernel beats library convolution + epilogue pass
+    for a layer with ``pixels`` output pixels.  The kernel has no split-K: with
+    few 64x64 output tiles and a long K loop the CUs run one block each and the
+    staging latency of every K step is exposed, which is where the library's
+    split-K kernels win.  Threshold fitted to per-layer timings on MI355X
+    (``tools/conv_bench.py``)."""
+    tiles = ((pixels + 63) // 64) * (cout // 64)
+    return tiles >= 4.5 * (k_total // 64)
+
+
 def _stream():
     import torch
 
@@ -68,6 +79,46 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0
                                   residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w,
                                   int(stride), cin, cout, 1 if relu else 0, code, _stream())
     check(rc, "tca_conv1x1_launch")
+    return out
+
+
+def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0, variant=0, out=None):
+    """``act(conv2d(x, weight) + bias (+ residual))`` as an implicit GEMM on the
+    MFMA kernel (square kernels, e.g. 3x3 with padding 1).
+
+    weight   fp16 ``[Cout, Cin, R, R]`` in channels-last memory format, i.e.
+             stored ``[Cout][R][R][Cin]`` - the GEMM's K order
+    Cin must be a multiple of 64 (every K step of 64 lies inside one tap) and
+    Cout a multiple of 64.
+    """
+    import torch
+
+    if x.dtype != torch.float16 or weight.dtype != torch.float16:
+        raise TypeError("conv2d takes fp16 tensors")
+    if not _is_nhwc(x):
+        raise ValueError("x must be a channels-last [N, C, H, W] tensor")
+    n, cin, h, w = x.shape
+    cout, wcin, r, s = weight.shape
+    if wcin != cin or r != s:
+        raise ValueError("weight must be [Cout, Cin, R, R] with Cin matching x")
+    if not weight.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("weight must be in channels-last memory format")
+    oh, ow = (h + 2 * padding - r) // stride + 1, (w + 2 * padding - r) // stride + 1
+    if out is None:
+        out = torch.empty((n, cout, oh, ow), dtype=torch.float16, device=x.device,
+                          memory_format=torch.channels_last)
+    elif tuple(out.shape) != (n, cout, oh, ow) or not _is_nhwc(out):
+        raise ValueError("out must be a channels-last tensor of the output shape")
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not _is_nhwc(residual)
+                                 or residual.dtype != torch.float16):
+        raise ValueError("residual must match the output (fp16, channels-last)")
+    if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
+        raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
+    code = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    rc = lib().tca_conv_gemm_launch(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, r,
+                                    int(stride), int(padding), cin, cout, 1 if relu else 0, code, _stream())
+    check(rc, "tca_conv_gemm_launch")
     return out
 
 
