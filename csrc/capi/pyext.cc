@@ -3,6 +3,7 @@
 //
 //   pack_bytes(seq_of_bytes) -> bytes          K7 on the host
 //   unpack_bytes(buffer, count) -> list[bytes] K8 on the host (count < 0: all)
+//   GrpcFront                                  native gRPC serving front (py_grpc_front.cc)
 //
 // The reference does both with a per-element Python loop
 // (`tritonclient/utils/__init__.py:227-246,267-276`).
@@ -188,4 +189,14 @@ static PyMethodDef kMethods[] = {
 static struct PyModuleDef kModule = {PyModuleDef_HEAD_INIT, "_tca_pyext", "native codec helpers", -1, kMethods,
                                      nullptr, nullptr, nullptr, nullptr};
 
-PyMODINIT_FUNC PyInit__tca_pyext(void) { return PyModule_Create(&kModule); }
+extern "C" int tca_register_grpc_front(PyObject* module);  // py_grpc_front.cc
+
+PyMODINIT_FUNC PyInit__tca_pyext(void) {
+  PyObject* module = PyModule_Create(&kModule);
+  if (module == nullptr) return nullptr;
+  if (tca_register_grpc_front(module) < 0) {
+    Py_DECREF(module);
+    return nullptr;
+  }
+  return module;
+}

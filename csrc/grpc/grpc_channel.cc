@@ -1,6 +1,8 @@
 // gRPC channel on the in-tree HTTP/2 engine (see tca/grpc_channel.h).
 #include "tca/grpc_channel.h"
 
+#include "tca/grpc_compress.h"
+
 #include <arpa/inet.h>
 #include <fcntl.h>
 #include <netdb.h>
@@ -253,7 +255,7 @@ void GrpcChannel::OpenCallStream(uint64_t id, Call* call) {
   h.push_back({"te", "trailers"});
   h.push_back({"content-type", "application/grpc"});
   h.push_back({"user-agent", "tca-grpc-cpp/1.0"});
-  h.push_back({"grpc-accept-encoding", "identity"});
+  h.push_back({"grpc-accept-encoding", "identity,deflate,gzip"});
   if (call->timeout_us) h.push_back({"grpc-timeout", GrpcTimeout(call->timeout_us)});
   for (const auto& kv : call->metadata) {
     std::string name = kv.first;
@@ -268,10 +270,10 @@ void GrpcChannel::OpenCallStream(uint64_t id, Call* call) {
   by_stream_[call->stream] = id;
 }
 
-void GrpcChannel::SendMessage(uint64_t call_id, std::string&& serialized, bool last) {
+void GrpcChannel::SendMessage(uint64_t call_id, std::string&& serialized, bool last, bool compressed) {
   std::string framed;
   framed.reserve(serialized.size() + 5);
-  framed.push_back(0);
+  framed.push_back(compressed ? 1 : 0);
   const uint32_t n = static_cast<uint32_t>(serialized.size());
   const char len[4] = {static_cast<char>(n >> 24), static_cast<char>(n >> 16), static_cast<char>(n >> 8),
                        static_cast<char>(n)};
@@ -317,7 +319,7 @@ void GrpcChannel::OnHeaders(uint32_t stream, h2::HeaderList&& headers, bool end_
     if (h.name == ":status") call.http_status = std::atoi(h.value.c_str());
     else if (h.name == "grpc-status") { call.grpc_status = std::atoi(h.value.c_str()); call.got_status = true; }
     else if (h.name == "grpc-message") call.grpc_message = PercentDecode(h.value);
-    else if (h.name == "grpc-encoding" && h.value != "identity") {
+    else if (h.name == "grpc-encoding" && h.value != "identity" && h.value != "gzip" && h.value != "deflate") {
       conn_->ResetStream(stream, h2::kCancel);
       Finish(id, kGrpcUnimplemented, "response compression '" + h.value + "' is not supported by this client");
       return;
@@ -345,14 +347,18 @@ void GrpcChannel::OnData(uint32_t stream, const uint8_t* data, size_t len, bool 
     const uint8_t* p = reinterpret_cast<const uint8_t*>(call.rbuf.data()) + off;
     const size_t n = (static_cast<size_t>(p[1]) << 24) | (static_cast<size_t>(p[2]) << 16) |
                      (static_cast<size_t>(p[3]) << 8) | p[4];
-    if (p[0] != 0) {
-      conn_->ResetStream(stream, h2::kCancel);
-      Finish(id, kGrpcUnimplemented, "compressed gRPC messages are not supported by this client");
-      return;
-    }
     if (call.rbuf.size() - off - 5 < n) break;
     std::string message(call.rbuf, off + 5, n);
     off += 5 + n;
+    if (p[0] != 0) {
+      std::string plain;
+      if (!grpcz::Decompress(message.data(), message.size(), &plain).IsOk()) {
+        conn_->ResetStream(stream, h2::kCancel);
+        Finish(id, kGrpcInternal, "corrupt compressed response message");
+        return;
+      }
+      message.swap(plain);
+    }
     if (call.events.on_message) {
       // the handler may cancel or finish the call: look it up again afterwards
       auto handler = call.events.on_message;

@@ -8,6 +8,7 @@
 #include <sstream>
 
 #include "tca/base64.h"
+#include "tca/grpc_compress.h"
 #include "tca/json.h"
 #include "tca/pbjson.h"
 #include "tca/pbwire.h"
@@ -451,6 +452,18 @@ class InferResultGrpc : public InferResult {
   Error status_;
 };
 
+// Compresses `request` in place and names the algorithm in the call metadata.
+Error ApplyCompression(GrpcCompression alg, std::string* request, Headers* metadata, bool* compressed) {
+  *compressed = false;
+  if (alg == GrpcCompression::NONE) return Error::Success();
+  std::string packed;
+  TCA_RETURN_IF_ERROR(grpcz::Compress(request->data(), request->size(), alg == GrpcCompression::GZIP, &packed));
+  request->swap(packed);
+  (*metadata)["grpc-encoding"] = alg == GrpcCompression::GZIP ? "gzip" : "deflate";
+  *compressed = true;
+  return Error::Success();
+}
+
 Error StatusToError(int status, const std::string& message) {
   if (status == kGrpcOk) return Error::Success();
   return Error(message.empty() ? ("gRPC status " + std::to_string(status)) : message, status);
@@ -467,6 +480,7 @@ struct InferenceServerGrpcClient::StreamState {
   int status = 0;
   std::string message;
   bool enable_stats = true;
+  GrpcCompression compression = GrpcCompression::NONE;
   OnCompleteFn callback;
   std::deque<RequestTimers> timers;  // FIFO, one per request in flight (non-decoupled accounting)
 };
@@ -517,7 +531,7 @@ size_t InferenceServerGrpcClient::GetNumCachedChannels() {
 }
 
 Error InferenceServerGrpcClient::Unary(const std::string& method, const std::string& request, const Headers& headers,
-                                       uint64_t timeout_us, std::string* response) {
+                                       uint64_t timeout_us, std::string* response, bool compressed) {
   struct Sync {
     std::mutex mu;
     std::condition_variable cv;
@@ -536,7 +550,7 @@ Error InferenceServerGrpcClient::Unary(const std::string& method, const std::str
     sync->cv.notify_all();
   };
   const uint64_t call = channel_->StartCall(method, headers, timeout_us, std::move(ev));
-  channel_->SendMessage(call, std::string(request), true);
+  channel_->SendMessage(call, std::string(request), true, compressed);
   std::unique_lock<std::mutex> lk(sync->mu);
   sync->cv.wait(lk, [&] { return sync->done; });
   if (sync->status != kGrpcOk) return StatusToError(sync->status, sync->message);
@@ -748,16 +762,17 @@ Error InferenceServerGrpcClient::Infer(InferResult** result, const InferOptions&
                                        const std::vector<InferInput*>& inputs,
                                        const std::vector<const InferRequestedOutput*>& outputs, const Headers& headers,
                                        GrpcCompression compression_algorithm) {
-  if (compression_algorithm != GrpcCompression::NONE)
-    return Error("message compression is not compiled into this gRPC client");
   RequestTimers timers;
   timers.CaptureTimestamp(RequestTimers::Kind::REQUEST_START);
   timers.CaptureTimestamp(RequestTimers::Kind::SEND_START);
   std::string request;
   TCA_RETURN_IF_ERROR(EncodeInferRequest(&request, options, inputs, outputs));
+  Headers metadata = headers;
+  bool compressed = false;
+  TCA_RETURN_IF_ERROR(ApplyCompression(compression_algorithm, &request, &metadata, &compressed));
   timers.CaptureTimestamp(RequestTimers::Kind::SEND_END);
   std::string response;
-  const Error e = Unary("ModelInfer", request, headers, options.client_timeout_, &response);
+  const Error e = Unary("ModelInfer", request, metadata, options.client_timeout_, &response, compressed);
   timers.CaptureTimestamp(RequestTimers::Kind::RECV_START);
   if (!e.IsOk()) {
     *result = nullptr;
@@ -777,13 +792,14 @@ Error InferenceServerGrpcClient::AsyncInfer(OnCompleteFn callback, const InferOp
                                             const std::vector<const InferRequestedOutput*>& outputs,
                                             const Headers& headers, GrpcCompression compression_algorithm) {
   if (callback == nullptr) return Error("Callback function must be provided along with AsyncInfer() call.");
-  if (compression_algorithm != GrpcCompression::NONE)
-    return Error("message compression is not compiled into this gRPC client");
   auto timers = std::make_shared<RequestTimers>();
   timers->CaptureTimestamp(RequestTimers::Kind::REQUEST_START);
   timers->CaptureTimestamp(RequestTimers::Kind::SEND_START);
   std::string request;
   TCA_RETURN_IF_ERROR(EncodeInferRequest(&request, options, inputs, outputs));
+  Headers metadata = headers;
+  bool compressed = false;
+  TCA_RETURN_IF_ERROR(ApplyCompression(compression_algorithm, &request, &metadata, &compressed));
   auto response = std::make_shared<std::string>();
   GrpcChannel::CallEvents ev;
   ev.on_message = [response, timers](std::string&& m) {
@@ -798,8 +814,8 @@ Error InferenceServerGrpcClient::AsyncInfer(OnCompleteFn callback, const InferOp
     if (status == kGrpcOk && !exiting_.load()) UpdateInferStat(*timers);
     callback(r);
   };
-  const uint64_t call = channel_->StartCall("ModelInfer", headers, options.client_timeout_, std::move(ev));
-  channel_->SendMessage(call, std::move(request), true);
+  const uint64_t call = channel_->StartCall("ModelInfer", metadata, options.client_timeout_, std::move(ev));
+  channel_->SendMessage(call, std::move(request), true, compressed);
   timers->CaptureTimestamp(RequestTimers::Kind::SEND_END);
   return Error::Success();
 }
@@ -882,9 +898,11 @@ Error InferenceServerGrpcClient::StartStream(OnCompleteFn callback, bool enable_
                  "single active stream at a given time.");
   }
   if (callback == nullptr) return Error("Callback function must be provided along with StartStream() call.");
-  if (compression_algorithm != GrpcCompression::NONE)
-    return Error("message compression is not compiled into this gRPC client");
   auto st = std::make_shared<StreamState>();
+  st->compression = compression_algorithm;
+  Headers metadata = headers;
+  if (compression_algorithm != GrpcCompression::NONE)
+    metadata["grpc-encoding"] = compression_algorithm == GrpcCompression::GZIP ? "gzip" : "deflate";
   st->enable_stats = enable_stats;
   st->callback = std::move(callback);
   GrpcChannel::CallEvents ev;
@@ -921,7 +939,7 @@ Error InferenceServerGrpcClient::StartStream(OnCompleteFn callback, bool enable_
     st->done = true;
     st->cv.notify_all();
   };
-  st->call = channel_->StartCall("ModelStreamInfer", headers, stream_timeout, std::move(ev));
+  st->call = channel_->StartCall("ModelStreamInfer", metadata, stream_timeout, std::move(ev));
   stream_ = st;
   return Error::Success();
 }
@@ -954,12 +972,17 @@ Error InferenceServerGrpcClient::AsyncStreamInfer(const InferOptions& options, c
   timers.CaptureTimestamp(RequestTimers::Kind::SEND_START);
   std::string request;
   TCA_RETURN_IF_ERROR(EncodeInferRequest(&request, options, inputs, outputs));
+  bool compressed = false;
+  if (stream_->compression != GrpcCompression::NONE) {
+    Headers unused;
+    TCA_RETURN_IF_ERROR(ApplyCompression(stream_->compression, &request, &unused, &compressed));
+  }
   timers.CaptureTimestamp(RequestTimers::Kind::SEND_END);
   if (stream_->enable_stats) {
     std::lock_guard<std::mutex> lk(stream_->mu);
     stream_->timers.push_back(timers);
   }
-  channel_->SendMessage(stream_->call, std::move(request), false);
+  channel_->SendMessage(stream_->call, std::move(request), false, compressed);
   return Error::Success();
 }
 

@@ -57,8 +57,10 @@ class GrpcChannel {
   // Starts a call on "/inference.GRPCInferenceService/<method>".  Never fails
   // synchronously: connection problems surface through on_done.
   uint64_t StartCall(const std::string& method, const Headers& metadata, uint64_t timeout_us, CallEvents events);
-  // Sends one request message; `last` half-closes the call.
-  void SendMessage(uint64_t call, std::string&& serialized, bool last);
+  // Sends one request message; `last` half-closes the call.  `compressed` marks
+  // a payload the caller compressed with the algorithm it announced in the
+  // call's "grpc-encoding" metadata.
+  void SendMessage(uint64_t call, std::string&& serialized, bool last, bool compressed = false);
   void CloseSend(uint64_t call);
   void Cancel(uint64_t call);
 

@@ -11,9 +11,9 @@
 // Differences by design: transport and protobuf coding are in-tree (tca/h2.h,
 // tca/pbwire.h) because the toolchain has neither grpc++ nor protobuf; control
 // RPC answers are returned as JSON text with the .proto field names (the shape
-// the HTTP client returns) instead of generated message objects; TLS and
-// message compression are not compiled in (an SSL request fails at Create, a
-// compression request is rejected per call).
+// the HTTP client returns) instead of generated message objects; request
+// compression (gzip / deflate) is done with zlib; TLS is not compiled in (an
+// SSL request fails at Create).
 #pragma once
 
 #include <memory>
@@ -118,7 +118,7 @@ class InferenceServerGrpcClient : public InferenceServerClient {
  private:
   InferenceServerGrpcClient(std::shared_ptr<GrpcChannel> channel, bool verbose);
   Error Unary(const std::string& method, const std::string& request, const Headers& headers, uint64_t timeout_us,
-              std::string* response);
+              std::string* response, bool compressed = false);
   Error JsonCall(const std::string& method, const std::string& request_json, const Headers& headers,
                  std::string* response_json);
 

@@ -533,3 +533,49 @@ def test_memory_growth_new_client_per_request(server):
             c.infer("custom_identity_int32", [inp])
     time.sleep(0.1)
     assert threading.active_count() <= before + 2
+
+
+@pytest.mark.parametrize("impl", ["native", "grpcio"])
+def test_both_grpc_fronts_serve_the_same_surface(impl):
+    """The native HTTP/2 front and the stock Python gRPC server are
+    interchangeable behind ``Server(grpc_impl=...)``."""
+    import queue
+
+    import tritonclient.grpc as grpcclient
+    from triton_client_amd.server import Server
+    from tritonclient.utils import InferenceServerException
+
+    with Server(models=["simple", "simple_sequence", "repeat_int32"], enable_http=False, grpc_impl=impl) as srv:
+        with grpcclient.InferenceServerClient(srv.grpc_url) as c:
+            assert c.is_server_live() and c.is_model_ready("simple")
+            assert c.get_model_config("simple").config.name == "simple"
+            a = np.arange(16, dtype=np.int32).reshape(1, 16)
+            b = np.full((1, 16), 3, dtype=np.int32)
+            inputs = [grpcclient.InferInput("INPUT0", [1, 16], "INT32").set_data_from_numpy(a),
+                      grpcclient.InferInput("INPUT1", [1, 16], "INT32").set_data_from_numpy(b)]
+            r = c.infer("simple", inputs, compression_algorithm="gzip")
+            np.testing.assert_array_equal(r.as_numpy("OUTPUT0"), a + b)
+            with pytest.raises(InferenceServerException, match="unknown model"):
+                c.infer("nope", inputs)
+            # async + stream (decoupled: one request, five responses + the empty final one)
+            done = queue.Queue()
+            c.async_infer("simple", inputs, lambda result, error: done.put((result, error)))
+            result, error = done.get(timeout=20)
+            assert error is None
+            np.testing.assert_array_equal(result.as_numpy("OUTPUT1"), a - b)
+            c.start_stream(lambda result, error: done.put((result, error)))
+            n = 5
+            c.async_stream_infer("repeat_int32", [
+                grpcclient.InferInput("IN", [n], "INT32").set_data_from_numpy(np.arange(n, dtype=np.int32)),
+                grpcclient.InferInput("DELAY", [n], "UINT32").set_data_from_numpy(np.zeros(n, dtype=np.uint32)),
+                grpcclient.InferInput("WAIT", [1], "UINT32").set_data_from_numpy(np.zeros(1, dtype=np.uint32)),
+            ], enable_empty_final_response=True)
+            got = []
+            while True:
+                result, error = done.get(timeout=20)
+                assert error is None
+                if result.get_response().parameters["triton_final_response"].bool_param:
+                    break
+                got.append(int(result.as_numpy("OUT")[0]))
+            c.stop_stream()
+            assert got == list(range(n))

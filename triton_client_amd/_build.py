@@ -9,7 +9,7 @@ on a CPU-only build host.
 Targets
 -------
 core   : libtca_core.so      (g++   – system shm, codec, base64 C ABI)
-pyext  : _tca_pyext*.so      (g++   – CPython BYTES pack/unpack)
+pyext  : _tca_pyext*.so      (g++   – CPython BYTES pack/unpack, native gRPC serving front)
 hip    : libtca_hip.so       (hipcc – hipshm + CDNA4 kernels)
 cpp    : build/libtcaclient.{a,so}, C++ examples, tests and the perf driver
 all    : everything above (default)
@@ -71,11 +71,12 @@ def build_core(force=False):
 def build_pyext(force=False):
     suffix = sysconfig.get_config_var("EXT_SUFFIX")
     out = LIBDIR / f"_tca_pyext{suffix}"
-    srcs = [CSRC / "capi" / "pyext.cc"]
+    srcs = [CSRC / "capi" / "pyext.cc", CSRC / "capi" / "py_grpc_front.cc", CSRC / "grpc" / "grpc_server.cc",
+            CSRC / "grpc" / "grpc_compress.cc", CSRC / "h2" / "hpack.cc", CSRC / "h2" / "connection.cc"]
     if force or _stale(out, srcs):
         LIBDIR.mkdir(exist_ok=True)
         inc = sysconfig.get_paths()["include"]
-        _compile_atomic(["g++", *CXXFLAGS, "-I", inc, "-shared", "-o", out, *srcs], out)
+        _compile_atomic(["g++", *CXXFLAGS, "-I", inc, "-shared", "-o", out, *srcs, "-pthread", "-lz"], out)
     return out
 
 

@@ -114,6 +114,21 @@ def hip():
     return _hip
 
 
+def pyext():
+    """The ``_tca_pyext`` CPython extension (built on demand): BYTES codec and
+    the native gRPC serving front."""
+    try:
+        from ._lib import _tca_pyext
+    except ImportError:
+        from . import _build
+
+        _build.build_pyext()
+        from ._lib import _tca_pyext
+    if not hasattr(_tca_pyext, "GrpcFront"):
+        raise ImportError("_tca_pyext was built without the gRPC front; rebuild: python -m triton_client_amd._build pyext")
+    return _tca_pyext
+
+
 def pyext_available():
     try:
         from ._lib import _tca_pyext  # noqa: F401

@@ -28,7 +28,7 @@ class Server:
     """In-process server.  ``http_port`` / ``grpc_port`` of 0 pick free ports."""
 
     def __init__(self, models=None, gpu=None, http_port=0, grpc_port=0, host="127.0.0.1", model_control="none",
-                 enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32):
+                 enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32, grpc_impl=None):
         self.core = InferenceCore(models=models, gpu=gpu, model_control=model_control)
         self.host = host
         self._http_port = http_port
@@ -37,6 +37,9 @@ class Server:
         self._enable_grpc = enable_grpc
         self._http_workers = http_workers
         self._grpc_workers = grpc_workers
+        # "native": C++ HTTP/2 reactors + asynchronous completion; "grpcio": the stock
+        # Python gRPC server.  Default from TCA_GRPC_IMPL, else native.
+        self._grpc_impl = (grpc_impl or os.environ.get("TCA_GRPC_IMPL") or "native").lower()
         self._loop = None
         self._thread = None
         self.http = None
@@ -52,9 +55,16 @@ class Server:
 
     def start(self):
         if self._enable_grpc:
-            from .grpc_front import GrpcFront
+            if self._grpc_impl == "native":
+                from .native_grpc_front import NativeGrpcFront
 
-            self.grpc = GrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers)
+                self.grpc = NativeGrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers)
+            elif self._grpc_impl == "grpcio":
+                from .grpc_front import GrpcFront
+
+                self.grpc = GrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers)
+            else:
+                raise ValueError(f"unknown gRPC implementation '{self._grpc_impl}' (native | grpcio)")
             self._grpc_port = self.grpc.start()
         if self._enable_http:
             from .http_front import HttpFront

@@ -22,6 +22,8 @@ def main(argv=None):
     ap.add_argument("--model-control-mode", default="none", choices=["none", "explicit"])
     ap.add_argument("--http-workers", type=int, default=16)
     ap.add_argument("--grpc-workers", type=int, default=32)
+    ap.add_argument("--grpc-impl", choices=["native", "grpcio"], default=None,
+                    help="gRPC front: native C++ HTTP/2 reactors (default) or the stock Python gRPC server")
     ap.add_argument("--announce", action="store_true", help="print one JSON line with the bound ports when ready")
     ap.add_argument("--exit-on-stdin-close", action="store_true")
     args = ap.parse_args(argv)
@@ -36,7 +38,7 @@ def main(argv=None):
             models += [n for n, c in MODEL_ZOO.items() if c.device == "gpu"]
     server = Server(models=models, gpu=args.gpu, http_port=args.http_port, grpc_port=args.grpc_port, host=args.host,
                     model_control=args.model_control_mode, http_workers=args.http_workers,
-                    grpc_workers=args.grpc_workers).start()
+                    grpc_workers=args.grpc_workers, grpc_impl=args.grpc_impl).start()
     if args.announce:
         print(json.dumps({"http_port": server._http_port, "grpc_port": server._grpc_port,
                           "models": [m["name"] for m in server.core.repository_index(True)],

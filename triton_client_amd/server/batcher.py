@@ -26,15 +26,29 @@ from .core import ServerError
 
 class _Item:
     __slots__ = ("req", "inputs", "batch", "stable", "requested", "ctx", "stats", "t_arrive", "version", "done",
-                 "response", "error", "t_queued")
+                 "response", "error", "t_queued", "callback")
 
-    def __init__(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version):
+    def __init__(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback=None):
         self.req, self.inputs, self.batch, self.stable = req, inputs, batch, stable
         self.requested, self.ctx, self.stats, self.t_arrive, self.version = requested, ctx, stats, t_arrive, version
-        self.done = threading.Event()
+        # blocking submitters wait on the event; asynchronous ones get a callback
+        self.done = threading.Event() if callback is None else None
+        self.callback = callback
         self.response = None
         self.error = None
         self.t_queued = time.perf_counter_ns()
+
+    def finish(self):
+        """Hand the outcome to whoever submitted the request."""
+        if self.callback is None:
+            self.done.set()
+            return
+        try:
+            self.callback(self.response, self.error)
+        except Exception:  # a broken transport callback must not stop the completer
+            import traceback
+
+            traceback.print_exc()
 
 
 class DynamicBatcher:
@@ -95,6 +109,11 @@ class DynamicBatcher:
             raise item.error
         return item.response
 
+    def submit_async(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback):
+        """Queue a request and return at once; ``callback(response, error)`` runs
+        on the completer thread (or the batcher thread when the launch fails)."""
+        self.q.put(_Item(req, inputs, max(1, batch), stable, requested, ctx, stats, t_arrive, version, callback))
+
     # ------------------------------------------------------------ batching
     def _next_group(self):
         first = self._held or self.q.get()
@@ -145,13 +164,13 @@ class DynamicBatcher:
                 for it in group:
                     it.error = err
                     it.stats.record_fail(time.perf_counter_ns() - it.t_arrive)
-                    it.done.set()
+                    it.finish()
             except Exception as e:  # keep serving after an unexpected failure
                 self._inflight.release()
                 err = ServerError(f"internal error while executing '{self.model.name}': {type(e).__name__}: {e}", 500)
                 for it in group:
                     it.error = err
-                    it.done.set()
+                    it.finish()
 
     def _static_buffers(self, total, in_name, in_dtype, in_tail, out_name):
         import torch
@@ -303,7 +322,7 @@ class DynamicBatcher:
                     it.error = e
                 except Exception as e:
                     it.error = ServerError(f"internal error: {type(e).__name__}: {e}", 500)
-                it.done.set()
+                it.finish()
 
     def _respond(self, it, final, requested, out_specs, dev_inputs):
         from .core import InferResponse, OutputTensor, PackedBytes

@@ -333,6 +333,9 @@ def _decode_json(datatype, shape, data, name):
     return np.array(flat, dtype=npdt).reshape(shape)
 
 
+ASYNC = object()  # returned by InferenceCore.infer when the answer comes through on_done
+
+
 class PackedBytes:
     """A BYTES tensor that already is in wire form (``<u32 len><bytes>`` per
     element), e.g. classification strings formatted by the GPU kernel.  Fronts
@@ -701,9 +704,21 @@ class InferenceCore:
             if lm.request_counter % int(every) == 0:
                 raise ServerError(f"injected failure for model '{lm.model.name}' (fail_every_n={every})", 500)
 
-    def infer(self, req: InferRequest):
+    def uses_batcher(self, name):
+        """Whether requests for ``name`` complete asynchronously (GPU model
+        behind the dynamic batcher)."""
+        with self._lock:
+            lm = self._loaded.get(name)
+        return lm is not None and lm.batcher is not None
+
+    def infer(self, req: InferRequest, on_done=None):
         """Run one request.  Returns an :class:`InferResponse` for ordinary
-        models, or an iterator of them for decoupled models."""
+        models, or an iterator of them for decoupled models.
+
+        With ``on_done`` and a model behind the dynamic batcher the request is
+        only queued: :data:`ASYNC` is returned and ``on_done(response, error)``
+        is called later from the completer thread, so transport threads never
+        block on the GPU."""
         t_arrive = time.perf_counter_ns()
         lm = self._get(req.model_name, req.model_version)
         model = lm.model
@@ -731,6 +746,10 @@ class InferenceCore:
             ctx.stable_inputs = stable
             if model.device == "gpu":
                 if lm.batcher is not None:
+                    if on_done is not None:
+                        lm.batcher.submit_async(req, inputs, batch, stable, requested, ctx, stats, t_arrive, version,
+                                                on_done)
+                        return ASYNC
                     return lm.batcher.submit(req, inputs, batch, stable, requested, ctx, stats, t_arrive, version)
                 return self._run_gpu_single(lm, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version)
             t1 = time.perf_counter_ns()
