@@ -46,7 +46,103 @@ def parse_args():
     ap.add_argument("--shared-memory", choices=["hip", "system", "none"], default="hip")
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--extra", action="store_true", help="also measure the wire path and the fan-out path")
+    ap.add_argument("--client", choices=["native", "python"], default=os.environ.get("TCA_BENCH_CLIENT", "native"),
+                    help="native: C++ load generator (tca_loadgen) over the in-tree gRPC/HTTP client; "
+                         "python: tritonclient-API threads in this process")
+    ap.add_argument("--connections", type=int, default=4, help="gRPC channels the native load generator spreads over")
     return ap.parse_args()
+
+
+LOADGEN = os.path.join(ROOT, "triton_client_amd", "_lib", "tca_loadgen")
+if not os.path.exists(LOADGEN):
+    LOADGEN = os.path.join(ROOT, "build", "bin", "tca_loadgen")
+
+
+def measure_native(args, url, device, dist, label):
+    """Closed loop driven by the C++ load generator.  This process only creates
+    the HIP shared-memory regions (filled by the HIP preprocessing kernel),
+    registers them and brackets the measured phase: the generator warms up,
+    prints READY, waits for the go line, then issues exactly steps x
+    requests-per-step requests with ``--concurrency`` outstanding."""
+    import subprocess
+
+    import numpy as np
+    import torch
+
+    from triton_client_amd.ops.preprocess import Preprocessor
+
+    if args.shared_memory != "hip":
+        raise SystemExit("--client native drives the hip shared-memory configuration; use --client python otherwise")
+    if not os.path.exists(LOADGEN):
+        raise SystemExit(f"{LOADGEN} is missing: run `python -m triton_client_amd._build cpp`")
+    import tritonclient.grpc as grpcclient
+    import tritonclient.utils.cuda_shared_memory as hipshm
+
+    b = args.batch
+    in_bytes, out_bytes = b * 3 * 224 * 224 * 2, b * 1000 * 4
+    rng = np.random.default_rng(1234 + device)
+    images = [rng.integers(0, 256, size=(375, 500, 3), dtype=np.uint8) for _ in range(b)]
+    pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=device)
+    control = grpcclient.InferenceServerClient(url if args.protocol == "grpc" else args.control_url)
+    regions = []
+    per_step = args.requests_per_step
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    proc = None
+    try:
+        for i in range(args.concurrency):
+            hin = hipshm.create_shared_memory_region(f"in_{device}_{i}", in_bytes, device)
+            hout = hipshm.create_shared_memory_region(f"out_{device}_{i}", out_bytes, device)
+            regions += [hin, hout]
+            pre(images, hin)  # HIP kernel writes the batch straight into the region
+            control.register_cuda_shared_memory(f"in_{device}_{i}", hipshm.get_raw_handle(hin), device, in_bytes)
+            control.register_cuda_shared_memory(f"out_{device}_{i}", hipshm.get_raw_handle(hout), device, out_bytes)
+        cmd = [LOADGEN, "-u", url, "-i", args.protocol, "-m", args.model, "-c", str(args.concurrency), "-b", str(b),
+               "--connections", str(args.connections), "--count", str(args.steps * per_step), "--warmup-count",
+               str(max(1, args.warmup) * per_step), "--wait-go",
+               "--shm-input", f"input:FP16:{b},3,224,224:in_{device}_{{slot}}:{in_bytes}",
+               "--shm-output", f"output:out_{device}_{{slot}}:{out_bytes}"]
+        proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        ready = proc.stdout.readline().strip()
+        if ready != "READY":
+            raise RuntimeError(f"load generator did not get ready: {ready!r}")
+        barrier()
+        t0 = time.perf_counter()
+        proc.stdin.write("GO\n")
+        proc.stdin.flush()
+        result = json.loads(proc.stdout.readline())
+        barrier()
+        elapsed = time.perf_counter() - t0
+        proc.wait(timeout=30)
+        if result["errors"] or result["requests"] != args.steps * per_step:
+            raise RuntimeError(f"load generator reported {result['errors']} errors "
+                               f"({result['requests']} of {args.steps * per_step} requests): {result['first_error']}")
+    finally:
+        if proc is not None and proc.poll() is None:
+            proc.kill()
+        for i in range(len(regions) // 2):
+            try:
+                control.unregister_cuda_shared_memory(f"in_{device}_{i}")
+                control.unregister_cuda_shared_memory(f"out_{device}_{i}")
+            except Exception:
+                pass
+        for r in regions:
+            hipshm.destroy_shared_memory_region(r)
+        control.close()
+        pre.close()
+    pcts = [result["p50_us"], result["p90_us"], result["p95_us"], result["p99_us"]]
+    if dist is not None:
+        t = torch.tensor([elapsed] + pcts, device=f"cuda:{device}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank bounds the job; percentiles: worst rank's
+        elapsed, pcts = float(t[0].item()), [float(v) for v in t[1:].tolist()]
+    world = dist.get_world_size() if dist is not None else 1
+    return {"label": label, "infer_per_sec": world * args.steps * per_step * b / elapsed, "elapsed_s": elapsed,
+            "p50_us": pcts[0], "p90_us": pcts[1], "p95_us": pcts[2], "p99_us": pcts[3],
+            "generator_infer_per_sec": result["infer_per_sec"]}
 
 
 class Worker:
@@ -244,7 +340,9 @@ def main():
                                       str(max(16, 2 * args.concurrency))])
     try:
         url = server.grpc_url if args.protocol == "grpc" else server.http_url
-        main_result = measure(args, url, device, dist, f"{args.protocol}+{args.shared_memory}shm")
+        args.control_url = server.grpc_url
+        run = measure_native if args.client == "native" else measure
+        main_result = run(args, url, device, dist, f"{args.protocol}+{args.shared_memory}shm")
         extras = {}
         if args.extra:
             for mode in ("none", "system"):
@@ -286,6 +384,8 @@ def main():
                 "requests_per_step_per_gpu": args.requests_per_step,
                 "protocol": args.protocol,
                 "shared_memory": args.shared_memory,
+                "load_generator": "tca_loadgen (C++, in-tree gRPC client)" if args.client == "native"
+                else "tritonclient-API threads (Python)",
                 "parallelism": f"dp{n} (one model instance per GPU, requests sharded)",
             },
         }

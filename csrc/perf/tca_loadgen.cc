@@ -1,10 +1,15 @@
 // Native load generator core: keeps `-c N` inference requests outstanding over
-// HTTP from ONE epoll thread (no interpreter in the loop) and reports
+// HTTP or gRPC from epoll reactor threads (no interpreter in the loop) and reports
 // throughput and latency percentiles as a JSON line.  The Python analyzer uses
 // it for high concurrency levels where per-request Python cost would bound the
 // offered load (`python -m triton_client_amd.perf --native`).
 //
-//   tca_loadgen -u host:port -m model [-x version] -c 64 -d 5.0 --warmup 1.0
+//   tca_loadgen -u host:port -m model [-x version] [-i http|grpc] -c 64 -d 5.0 --warmup 1.0
+//       --count N            issue and measure exactly N requests instead of -d seconds
+//       --warmup-count W     (with --count) W unmeasured requests first
+//       --wait-go            (with --count) print READY after the warm-up and start the
+//                            measured phase when a line arrives on stdin
+//       --connections M      gRPC: spread the slots over M channels (default 1)
 //       --shape NAME:DATATYPE:d0,d1,...      wire tensors (zero filled)
 //       --shm-input NAME:DATATYPE:dims:REGION:BYTES[:OFFSET]   registered shm input
 //       --shm-output NAME:REGION:BYTES[:OFFSET]
@@ -22,6 +27,7 @@
 #include <thread>
 
 #include "tca/codec.h"
+#include "tca/grpc_client.h"
 #include "tca/http_client.h"
 
 namespace tc = tca::client;
@@ -59,8 +65,10 @@ struct Slot {
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string url = "localhost:8000", model, version;
-  int concurrency = 1, batch = 1;
+  std::string url = "localhost:8000", model, version, protocol = "http";
+  int concurrency = 1, batch = 1, connections = 1;
+  long long count = 0, warmup_count = 0;
+  bool wait_go = false;
   double duration = 5.0, warmup = 1.0;
   std::vector<std::string> shapes, shm_in, shm_out;
   for (int i = 1; i < argc; ++i) {
@@ -68,6 +76,11 @@ int main(int argc, char** argv) {
     if (!std::strcmp(argv[i], "-u")) url = next();
     else if (!std::strcmp(argv[i], "-m")) model = next();
     else if (!std::strcmp(argv[i], "-x")) version = next();
+    else if (!std::strcmp(argv[i], "-i")) protocol = next();
+    else if (!std::strcmp(argv[i], "--count")) count = std::atoll(next());
+    else if (!std::strcmp(argv[i], "--warmup-count")) warmup_count = std::atoll(next());
+    else if (!std::strcmp(argv[i], "--wait-go")) wait_go = true;
+    else if (!std::strcmp(argv[i], "--connections")) connections = std::max(1, std::atoi(next()));
     else if (!std::strcmp(argv[i], "-c")) concurrency = std::atoi(next());
     else if (!std::strcmp(argv[i], "-b")) batch = std::atoi(next());
     else if (!std::strcmp(argv[i], "-d")) duration = std::atof(next());
@@ -78,9 +91,24 @@ int main(int argc, char** argv) {
     else { std::cerr << "unknown argument " << argv[i] << std::endl; return 2; }
   }
   if (model.empty() || concurrency < 1) { std::cerr << "usage: tca_loadgen -u url -m model -c N ..." << std::endl; return 2; }
+  for (auto& ch : protocol) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+  const bool use_grpc = protocol == "grpc";
+  if (!use_grpc && protocol != "http") { std::cerr << "-i must be http or grpc" << std::endl; return 2; }
   std::unique_ptr<tc::InferenceServerHttpClient> client;
-  tca::Error e = tc::InferenceServerHttpClient::Create(&client, url);
-  if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+  std::vector<std::unique_ptr<tc::InferenceServerGrpcClient>> grpc_clients;
+  tca::Error e;
+  if (use_grpc) {
+    for (int k = 0; k < connections; ++k) {
+      std::unique_ptr<tc::InferenceServerGrpcClient> g;
+      e = tc::InferenceServerGrpcClient::Create(&g, url, false, false, tc::SslOptions(), tc::KeepAliveOptions(),
+                                                /*use_cached_channel=*/false);
+      if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+      grpc_clients.push_back(std::move(g));
+    }
+  } else {
+    e = tc::InferenceServerHttpClient::Create(&client, url);
+    if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+  }
 
   // one request template per slot; `{slot}` in region names is replaced by the slot index
   std::vector<std::unique_ptr<Slot>> slots;
@@ -138,56 +166,126 @@ int main(int argc, char** argv) {
   std::condition_variable cv;
   std::vector<uint64_t> latencies;
   latencies.reserve(1 << 20);
-  std::atomic<bool> measuring{false}, stopping{false};
   std::atomic<uint64_t> errors{0};
-  int outstanding = 0;
   std::string first_error;
+  // phase state (guarded by mu)
+  bool record = false;      // completions of this phase go into `latencies`
+  bool open_ended = false;  // duration phase: re-issue until `stopping`
+  bool stopping = false;
+  long long to_issue = 0;   // count phase: requests still to be issued
+  long long to_finish = 0;  // count phase: completions still owed
+  int outstanding = 0;
+  uint64_t last_done_ns = 0;
 
   std::function<void(int)> issue = [&](int s) {
     Slot* slot = slots[s].get();
     slot->t0 = NowNs();
-    tca::Error se = client->AsyncInfer(
-        [&, s](tc::InferResult* r) {
-          const uint64_t t1 = NowNs();
-          tca::Error status = r->RequestStatus();
-          delete r;
-          bool again;
-          {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!status.IsOk()) {
-              ++errors;
-              if (first_error.empty()) first_error = status.Message();
-            } else if (measuring.load()) {
-              latencies.push_back(t1 - slots[s]->t0);
-            }
-            again = !stopping.load();
-            if (!again && --outstanding == 0) cv.notify_all();
+    auto on_done = [&, s](tc::InferResult* r) {
+      const uint64_t t1 = NowNs();
+      tca::Error status = r->RequestStatus();
+      delete r;
+      bool again = false;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        --outstanding;
+        last_done_ns = t1;
+        if (!status.IsOk()) {
+          ++errors;
+          if (first_error.empty()) first_error = status.Message();
+        } else if (record) {
+          latencies.push_back(t1 - slots[s]->t0);
+        }
+        if (open_ended) {
+          again = !stopping;
+        } else {
+          --to_finish;
+          if (to_issue > 0) {
+            --to_issue;
+            again = true;
           }
-          if (again) issue(s);  // re-submitted from the reactor thread: zero idle time per slot
-        },
-        options, slot->in_ptrs, slot->out_ptrs);
+        }
+        if (again) ++outstanding;
+        if (!again && (outstanding == 0 || (!open_ended && to_finish <= 0))) cv.notify_all();
+      }
+      if (again) issue(s);  // re-submitted from the reactor thread: zero idle time per slot
+    };
+    tca::Error se = use_grpc ? grpc_clients[s % grpc_clients.size()]->AsyncInfer(on_done, options, slot->in_ptrs,
+                                                                                slot->out_ptrs)
+                             : client->AsyncInfer(on_done, options, slot->in_ptrs, slot->out_ptrs);
     if (!se.IsOk()) {
       std::lock_guard<std::mutex> lk(mu);
       ++errors;
       if (first_error.empty()) first_error = se.Message();
-      if (--outstanding == 0) cv.notify_all();
+      --outstanding;
+      if (!open_ended) --to_finish;
+      cv.notify_all();
     }
   };
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    outstanding = concurrency;
-  }
-  for (int s = 0; s < concurrency; ++s) issue(s);
-  std::this_thread::sleep_for(std::chrono::duration<double>(warmup));
-  const uint64_t start = NowNs();
-  measuring.store(true);
-  std::this_thread::sleep_for(std::chrono::duration<double>(duration));
-  measuring.store(false);
-  const uint64_t end = NowNs();
-  stopping.store(true);
-  {
+
+  // Runs exactly `n` requests (never more than `concurrency` outstanding) and
+  // returns the time from the first submission to the last completion.
+  auto run_count = [&](long long n, bool measured) -> double {
+    const int first_wave = static_cast<int>(std::min<long long>(n, concurrency));
+    uint64_t t_start;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      record = measured;
+      open_ended = false;
+      stopping = false;
+      to_finish = n;
+      to_issue = n - first_wave;
+      outstanding = first_wave;
+      t_start = NowNs();
+    }
+    for (int s = 0; s < first_wave; ++s) issue(s);
     std::unique_lock<std::mutex> lk(mu);
-    cv.wait_for(lk, std::chrono::seconds(30), [&] { return outstanding == 0; });
+    cv.wait_for(lk, std::chrono::seconds(900), [&] { return to_finish <= 0 && outstanding == 0; });
+    return (last_done_ns - t_start) / 1e9;
+  };
+  // Time-based: warm up, then record for `seconds`.
+  auto run_duration = [&](double warm_s, double seconds) -> double {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      record = false;
+      open_ended = true;
+      stopping = false;
+      outstanding = concurrency;
+    }
+    for (int s = 0; s < concurrency; ++s) issue(s);
+    std::this_thread::sleep_for(std::chrono::duration<double>(warm_s));
+    uint64_t t0;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      record = true;
+      t0 = NowNs();
+    }
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    uint64_t t1;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      record = false;
+      t1 = NowNs();
+      stopping = true;
+    }
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait_for(lk, std::chrono::seconds(60), [&] { return outstanding == 0; });
+    return (t1 - t0) / 1e9;
+  };
+
+  double secs = 0;
+  if (count > 0) {
+    if (warmup_count > 0) run_count(warmup_count, false);
+    if (wait_go) {
+      // two-phase protocol for a driver that brackets the measured phase with its
+      // own barriers: announce readiness, start on the first line read from stdin
+      std::printf("READY\n");
+      std::fflush(stdout);
+      std::string line;
+      if (!std::getline(std::cin, line)) return 1;
+    }
+    secs = run_count(count, true);
+  } else {
+    secs = run_duration(warmup, duration);
   }
   std::vector<uint64_t> lat;
   {
@@ -202,13 +300,12 @@ int main(int argc, char** argv) {
   };
   double sum = 0;
   for (uint64_t v : lat) sum += static_cast<double>(v);
-  const double secs = (end - start) / 1e9;
   std::printf(
       "{\"requests\": %zu, \"errors\": %llu, \"duration_s\": %.4f, \"requests_per_sec\": %.2f, \"infer_per_sec\": %.2f, "
       "\"avg_us\": %.1f, \"p50_us\": %.1f, \"p90_us\": %.1f, \"p95_us\": %.1f, \"p99_us\": %.1f, \"concurrency\": %d, "
-      "\"first_error\": \"%s\"}\n",
+      "\"protocol\": \"%s\", \"first_error\": \"%s\"}\n",
       lat.size(), static_cast<unsigned long long>(errors.load()), secs, lat.size() / secs, lat.size() * batch / secs,
       lat.empty() ? 0.0 : sum / lat.size() / 1e3, pct(50), pct(90), pct(95), pct(99), concurrency,
-      first_error.substr(0, 200).c_str());
+      protocol.c_str(), first_error.substr(0, 200).c_str());
   return 0;
 }

@@ -113,6 +113,16 @@ def build_cpp(force=False):
         return None
     BUILD.mkdir(exist_ok=True)
     _run(["make", "-C", CSRC, "-j8", f"BUILD={BUILD}"] + (["-B"] if force else []))
+    # the load generator is needed at run time (bench.py, perf --native): keep a copy
+    # next to the shared objects, which is the directory that travels with the package
+    loadgen = BUILD / "bin" / "tca_loadgen"
+    if loadgen.exists():
+        LIBDIR.mkdir(exist_ok=True)
+        tmp = LIBDIR / f"tca_loadgen.tmp{os.getpid()}"
+        shutil.copy2(loadgen, tmp)
+        if shutil.which("strip"):
+            subprocess.call(["strip", str(tmp)])
+        os.replace(tmp, LIBDIR / "tca_loadgen")
     return BUILD
 
 
