@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "tca/grpc_client.h"
 #include "tca/http_client.h"
 
 namespace tc = tca::client;
@@ -60,6 +61,16 @@ inline CommonFlags ParseCommonFlags(int argc, char** argv) {
 inline std::unique_ptr<tc::InferenceServerHttpClient> MakeClient(const CommonFlags& f) {
   std::unique_ptr<tc::InferenceServerHttpClient> client;
   FAIL_IF_ERR(tc::InferenceServerHttpClient::Create(&client, f.url, f.verbose), "unable to create http client");
+  return client;
+}
+
+inline std::unique_ptr<tc::InferenceServerGrpcClient> MakeGrpcClient(
+    const CommonFlags& f, const tc::KeepAliveOptions& keepalive = tc::KeepAliveOptions(), bool cached = true) {
+  std::unique_ptr<tc::InferenceServerGrpcClient> client;
+  // -u defaults to the HTTP port: the gRPC examples move it to 8001
+  const std::string url = f.url == "localhost:8000" ? "localhost:8001" : f.url;
+  FAIL_IF_ERR(tc::InferenceServerGrpcClient::Create(&client, url, f.verbose, false, tc::SslOptions(), keepalive, cached),
+              "unable to create grpc client");
   return client;
 }
 

@@ -69,6 +69,37 @@ CPP_EXAMPLES = [
 ]
 
 
+GRPC_CPP_EXAMPLES = [
+    "simple_grpc_infer_client", "simple_grpc_async_infer_client", "simple_grpc_string_infer_client",
+    "simple_grpc_shm_client", "simple_grpc_health_metadata", "simple_grpc_model_control",
+    "simple_grpc_sequence_sync_infer_client", "simple_grpc_sequence_stream_infer_client",
+    "simple_grpc_custom_repeat", "simple_grpc_keepalive_client", "simple_grpc_custom_args_client",
+]
+
+
+@pytest.mark.parametrize("name", GRPC_CPP_EXAMPLES)
+def test_cpp_grpc_examples(built, server, name):
+    out = _run([os.path.join(built, name), "-u", server.grpc_url])
+    assert "PASS" in out
+
+
+@pytest.mark.parametrize("name,extra", [("simple_grpc_infer_client", ["-C", "gzip"]),
+                                        ("simple_grpc_sequence_sync_infer_client", ["-d"]),
+                                        ("simple_grpc_sequence_stream_infer_client", ["-d"])])
+def test_cpp_grpc_example_variants(built, server, name, extra):
+    assert "PASS" in _run([os.path.join(built, name), "-u", server.grpc_url, *extra])
+
+
+def test_native_loadgen_grpc_fixed_count(built, server):
+    import json
+
+    out = _run([os.path.join(built, "tca_loadgen"), "-u", server.grpc_url, "-i", "grpc", "-m", "simple", "-c", "8",
+                "--count", "500", "--warmup-count", "50", "--connections", "2", "--shape", "INPUT0:INT32:1,16",
+                "--shape", "INPUT1:INT32:1,16"])
+    stats = json.loads(out.strip().splitlines()[-1])
+    assert stats["errors"] == 0 and stats["requests"] == 500 and stats["protocol"] == "grpc"
+
+
 @pytest.mark.parametrize("name", CPP_EXAMPLES)
 def test_cpp_examples(built, server, name):
     exe = os.path.join(built, name)
