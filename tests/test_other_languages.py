@@ -44,8 +44,8 @@ def test_java_sources_are_structurally_sound():
         assert package == os.path.dirname(rel).replace(os.sep, "."), rel
         assert re.search(r"\b(class|enum|interface)\s+%s\b" % os.path.basename(rel)[:-5], text), rel
         # strip strings, chars and comments, then delimiters must balance
-        code = re.sub(r'"(\\.|[^"\\])*"', '""', text)
-        code = re.sub(r"'(\\.|[^'\\])'", "''", code)
+        code = re.sub(r"'(\\.|[^'\\])'", "''", text)  # char literals first: '"' would confuse the string pass
+        code = re.sub(r'"(\\.|[^"\\])*"', '""', code)
         code = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
         code = re.sub(r"//[^\n]*", "", code)
         for open_c, close_c in ("{}", "()", "[]"):
