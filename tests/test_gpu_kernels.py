@@ -313,3 +313,24 @@ def test_conv3x3_exact_integer_taps(torch):
     got = conv.conv2d(x, wt, None, None, relu=False, stride=1, padding=1, variant="64x64")
     ref = torch.nn.functional.conv2d(x.float(), wt.float(), None, stride=1, padding=1)
     assert torch.equal(got.float(), ref)
+
+
+def test_batched_copy_many_entries_and_alignments(torch):
+    from triton_client_amd.ops.copy import batched_copy
+
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    src = torch.randint(0, 255, (200, 70001), device="cuda", dtype=torch.uint8, generator=gen)
+    dst = torch.zeros_like(src)
+    sizes = [70001 if i % 3 else 4096 + i for i in range(150)]  # more than one launch (64 entries each)
+    triples = []
+    for i, n in enumerate(sizes):
+        shift = i % 5  # odd source/destination offsets: the byte path
+        triples.append((src[i].data_ptr() + shift, dst[i].data_ptr() + shift, n - shift))
+    batched_copy(triples)
+    torch.cuda.synchronize()
+    for i, n in enumerate(sizes):
+        shift = i % 5
+        assert torch.equal(dst[i, shift:n], src[i, shift:n]), i
+        assert int(dst[i, n:].sum()) == 0 and int(dst[i, :shift].sum()) == 0
+    assert int(dst[150:].sum()) == 0
+    batched_copy([])  # no-op

@@ -24,6 +24,29 @@ from ..models import ModelError
 from .core import ServerError
 
 
+def _profiled(fn, tag):
+    """With TCA_PROFILE_DIR set, run a thread's main function under cProfile and
+    write ``<dir>/<tag>.prof`` when it returns (developer aid for finding
+    per-request Python cost)."""
+    import os
+
+    out = os.environ.get("TCA_PROFILE_DIR")
+    if not out:
+        return fn
+
+    def run():
+        import cProfile
+
+        prof = cProfile.Profile()
+        try:
+            prof.runcall(fn)
+        finally:
+            os.makedirs(out, exist_ok=True)
+            prof.dump_stats(os.path.join(out, f"{tag}.prof"))
+
+    return run
+
+
 class _Item:
     __slots__ = ("req", "inputs", "batch", "stable", "requested", "ctx", "stats", "t_arrive", "version", "done",
                  "response", "error", "t_queued", "callback")
@@ -69,8 +92,8 @@ class DynamicBatcher:
         self._inflight = threading.Semaphore(int(getattr(self.model, "max_inflight_batches", 2)))
         self._prewarm()
         self._threads = [
-            threading.Thread(target=self._batch_loop, name="tca-batcher", daemon=True),
-            threading.Thread(target=self._complete_loop, name="tca-completer", daemon=True),
+            threading.Thread(target=_profiled(self._batch_loop, "batcher"), name="tca-batcher", daemon=True),
+            threading.Thread(target=_profiled(self._complete_loop, "completer"), name="tca-completer", daemon=True),
         ]
         for t in self._threads:
             t.start()
@@ -229,34 +252,52 @@ class DynamicBatcher:
                 in_dtype = first.dtype
             tail = tuple(first.shape[1:])
             sbuf, obuf = self._static_buffers(total, in_name, in_dtype, tail, out_name)
+            from ..ops.copy import batched_copy
+
+            # gather: device-resident inputs (hipshm) go through ONE batched copy
+            # kernel, wire inputs through pinned H2D copies
             row = 0
+            row_bytes = sbuf[0].numel() * sbuf.element_size()
+            gather = []
             with torch.cuda.stream(stream):
                 for it in group:
                     x = it.inputs[in_name]
                     if isinstance(x, np.ndarray):
-                        x = torch.from_numpy(np.ascontiguousarray(x))
-                    sbuf[row: row + it.batch].copy_(x, non_blocking=True)
+                        sbuf[row: row + it.batch].copy_(torch.from_numpy(np.ascontiguousarray(x)), non_blocking=True)
+                    elif x.is_cuda and x.is_contiguous() and x.dtype == sbuf.dtype:
+                        gather.append((x.data_ptr(), sbuf.data_ptr() + row * row_bytes, it.batch * row_bytes))
+                    else:
+                        sbuf[row: row + it.batch].copy_(x, non_blocking=True)
                     row += it.batch
+            batched_copy(gather, stream)
             merged = {in_name: sbuf, "__out__" + out_name: obuf}
             out = model.execute(merged, group[0].ctx)[out_name]
+            # scatter the output rows into the requests' shm destinations, again in one launch
             row = 0
+            out_row_bytes = out[0].numel() * out.element_size()
+            scatter = []
             for it in group:
                 piece = out[row: row + it.batch]
-                row += it.batch
                 dev_inputs = {}
                 placed = False
                 for ro in it.requested:
                     dest = core._output_destination(lm, ro, out_specs[ro.name], it.batch)
                     if dest is not None:
-                        with torch.cuda.stream(stream):
-                            dest.copy_(piece, non_blocking=True)
+                        if dest.dtype == out.dtype and dest.is_contiguous():
+                            scatter.append((out.data_ptr() + row * out_row_bytes, dest.data_ptr(),
+                                            it.batch * out_row_bytes))
+                        else:
+                            with torch.cuda.stream(stream):
+                                dest.copy_(piece, non_blocking=True)
                         dev_inputs["__out__" + ro.name] = dest
                         placed = True
+                row += it.batch
                 if placed:
                     result = {out_name: dev_inputs["__out__" + out_name]}
                 else:
                     result = self._host_copies(it, {out_name: piece}, stream, own_static=True)
                 pending.append((it, dev_inputs, result))
+            batched_copy(scatter, stream)
         event = torch.cuda.Event()
         event.record(stream)
         self.completions.put((event, pending, total, t_exec, time.perf_counter_ns()))

@@ -241,6 +241,23 @@ class DeviceShmRegistry:
     def __init__(self):
         self._lock = threading.Lock()
         self._regions = {}
+        self._views = {}  # (region, datatype, shape, offset) -> torch view; building one costs ~20 us
+
+    def tensor_view(self, name, mapping, datatype, shape, offset):
+        """Torch view of a slice of a registered region, cached: requests of a
+        closed-loop client name the same slices over and over."""
+        key = (name, datatype, tuple(shape), offset)
+        view = self._views.get(key)
+        if view is None:
+            from ..utils import hip_shared_memory as hipshm
+
+            view = hipshm.mapping_as_torch(mapping, datatype, shape, offset)
+            with self._lock:
+                if name in self._regions and self._regions[name][2] is mapping:
+                    if len(self._views) > 65536:
+                        self._views.clear()
+                    self._views[key] = view
+        return view
 
     def register(self, name, raw_handle: bytes, device_id, byte_size):
         from ..utils import hip_shared_memory as hipshm
@@ -262,6 +279,8 @@ class DeviceShmRegistry:
             for n in names:
                 entry = self._regions.pop(n, None)
                 if entry is not None:
+                    for key in [k for k in self._views if k[0] == n]:
+                        del self._views[key]
                     try:
                         hipshm.close_shared_memory_region(entry[2])
                     except Exception:
@@ -649,7 +668,7 @@ class InferenceCore:
         if ref.offset + ref.byte_size > size:
             raise ServerError(f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
         if gpu and t.datatype != "BYTES":
-            return hipshm.mapping_as_torch(mapping, t.datatype, shape, ref.offset)
+            return self.devshm.tensor_view(ref.region, mapping, t.datatype, shape, ref.offset)
         host = hipshm.read_mapping(mapping, ref.offset, ref.byte_size)
         return _decode_wire(t.datatype, shape, host, t.name, model.name)
 
@@ -668,7 +687,7 @@ class InferenceCore:
             raise ServerError(
                 f"shared memory size specified with the request for output '{ro.name}' ({ro.shm.byte_size} bytes) "
                 f"should be at least {need} bytes to hold the results")
-        return hipshm.mapping_as_torch(entry[2], spec.datatype, shape, ro.shm.offset)
+        return self.devshm.tensor_view(ro.shm.region, entry[2], spec.datatype, shape, ro.shm.offset)
 
     def _sequence_ctx(self, lm, req):
         params = req.parameters

@@ -17,6 +17,7 @@ behaviour; selected with ``Server(grpc_impl="native")``.
 from __future__ import annotations
 
 import collections
+import os
 import threading
 from concurrent import futures
 
@@ -72,7 +73,19 @@ class NativeGrpcFront:
             if m.name in ("ModelInfer", "ModelStreamInfer"):
                 continue
             self._methods[m.name] = (getattr(pb, m.input_type.name), getattr(self._servicer, m.name))
-        self._front = pyext().GrpcFront(host, int(port), int(reactors), self._on_unary, self._on_stream_message,
+        on_unary = self._on_unary
+        self._prof = None
+        if os.environ.get("TCA_PROFILE_DIR"):  # developer aid: profile the reactor-side Python work
+            import cProfile
+
+            self._prof = cProfile.Profile()
+            lock = threading.Lock()
+
+            def on_unary(call, method, data, _inner=self._on_unary):
+                with lock:
+                    self._prof.runcall(_inner, call, method, data)
+
+        self._front = pyext().GrpcFront(host, int(port), int(reactors), on_unary, self._on_stream_message,
                                         self._on_stream_end, self._on_cancel)
 
     def start(self):
@@ -82,6 +95,10 @@ class NativeGrpcFront:
     def stop(self, grace=0.5):
         self._front.stop()
         self._pool.shutdown(wait=False)
+        if self._prof is not None:
+            out = os.environ["TCA_PROFILE_DIR"]
+            os.makedirs(out, exist_ok=True)
+            self._prof.dump_stats(os.path.join(out, "reactor.prof"))
 
     def stats(self):
         return self._front.stats()
