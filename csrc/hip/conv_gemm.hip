@@ -25,12 +25,18 @@
 // 64, v_mfma_f32_16x16x32_f16.  The weight tile is the MFMA A operand and the
 // activation tile the B operand, i.e. the wave computes Y^T fragments: each
 // lane then owns 4 CONSECUTIVE output channels of one pixel, which packs into
-// one 8-byte LDS store for the epilogue transpose.  Tiles are staged
-// global -> registers -> LDS with the next tile's loads in flight during the
-// MFMAs (two LDS stages when K > 64).  LDS rows are 128 bytes; the 16-byte
-// chunk index is XOR-ed with (row>>1)&7, which makes every ds_read_b128 of a
-// fragment (16 rows x 4 chunks per wave instruction) bank-conflict free for
-// the instruction's four 16-lane groups.
+// one 8-byte LDS store for the epilogue transpose.  Tiles are staged by
+// direct-to-LDS DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no
+// ds_write, zero fill of masked rows / padding taps by the buffer range check,
+// and - because every per-lane quantity is precomputed and the per-step
+// displacement is a scalar offset - three VALU instructions per activation
+// vector and none per weight vector inside the K loop.  Two or three LDS
+// stages, one raw s_barrier per K step, counted vmcnt.  A register-staged
+// variant (global -> VGPR -> ds_write) is kept for A/B measurements and for
+// tensors beyond the DMA path's 2 GiB offsets.  LDS rows are 128 bytes; the
+// 16-byte chunk index is XOR-ed with (row>>1)&7, which makes every
+// ds_read_b128 of a fragment (16 rows x 4 chunks per wave instruction)
+// bank-conflict free for the instruction's four 16-lane groups.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -72,12 +78,29 @@ __device__ __forceinline__ long long InRow(const RowMap& map, int m) {
 // 16-byte chunk position inside a 128-byte LDS row
 __device__ __forceinline__ int Swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <int BM, int BN, bool kSpatial>
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+
+// Byte offset no activation descriptor reaches (the host keeps them below
+// 2 GiB): a lane that must contribute zeros - a row past M, a tap in the
+// padding - issues its DMA with this offset and the buffer range check
+// writes zeros into LDS for it.
+constexpr unsigned kOutOfRange = 0x80000000u;
+
+// One wave-wide 16-byte-per-lane copy global -> LDS without passing through
+// registers: lane l's bytes land at `lds_base` (wave-uniform) + 16 * l and come
+// from descriptor base + voffset (per lane) + soffset (wave-uniform).
+__device__ __forceinline__ void DmaToLds(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset, _Float16* lds_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, reinterpret_cast<lds_ptr_t>(reinterpret_cast<uintptr_t>(lds_base)), 16,
+                                           static_cast<int>(voffset), soffset, 0, 0);
+}
+
+template <int BM, int BN, bool kSpatial, bool kGlds>
 __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias,
                                                           const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ Y, int M, int N, int K, int relu,
-                                                          RowMap map, int tiles_n, int xcd_chunk) {
+                                                          RowMap map, int tiles_n, int xcd_chunk, unsigned x_bytes,
+                                                          int stages) {
   constexpr int kAVecs = BM * 8 / kThreads;  // 16-byte vectors per thread and stage (activation tile)
   constexpr int kWVecs = BN * 8 / kThreads;  // (weight tile)
   constexpr int kMI = BM / 32;               // 16-wide fragments per wave along m
@@ -97,42 +120,128 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  // the wave index as a scalar: LDS-DMA destinations and fragment bases stay in SGPR arithmetic
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1;  // wave row (m)
   const int wn = wave & 1;   // wave column (n)
 
-  // staging assignment: vector v -> (row v/8, chunk v%8)
+  // ---- direct-to-LDS staging state -------------------------------------------------
+  // The LDS image of one wave instruction is linear (lane l lands at base + 16*l), so
+  // lane l LOADS the 16-byte chunk whose swizzled place it fills.  Everything per
+  // lane is computed once: a byte offset per vector and, for RxR kernels, one bit per
+  // tap saying whether that tap reads inside the image.  A K step then costs a mask
+  // test and a select per activation vector and nothing per weight vector; the step's
+  // tap / channel displacement is wave-uniform and rides in the scalar offset.
+  unsigned a_off[kAVecs], a_taps[kAVecs], w_off[kWVecs];
+  // elements the activation descriptor's base sits BEFORE X, so the offset of the
+  // (possibly negative) top-left tap coordinate is never negative
+  const int lead = kSpatial ? (map.pad * map.in_w + map.pad) * map.cin : 0;
+  if constexpr (kGlds) {
+#pragma unroll
+    for (int i = 0; i < kAVecs; ++i) {
+      const int v = (i * 4 + wave) * 64 + lane;
+      const int row = v >> 3;
+      const int chunk = (v & 7) ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      if constexpr (kSpatial) {
+        const int img = m / map.ohw;
+        const int rem = m - img * map.ohw;
+        const int oh = rem / map.ow;
+        const int ow = rem - oh * map.ow;
+        const int ih0 = oh * map.stride - map.pad;
+        const int iw0 = ow * map.stride - map.pad;
+        const long long pixel = (static_cast<long long>(img) * map.in_h + ih0) * map.in_w + iw0;
+        a_off[i] = static_cast<unsigned>((pixel * map.cin + lead + chunk * 8) * 2);
+        unsigned rows_ok = 0, cols_ok = 0;
+        for (int k = 0; k < map.ksize; ++k) {
+          rows_ok |= static_cast<unsigned>(static_cast<unsigned>(ih0 + k) < static_cast<unsigned>(map.in_h)) << k;
+          cols_ok |= static_cast<unsigned>(static_cast<unsigned>(iw0 + k) < static_cast<unsigned>(map.in_w)) << k;
+        }
+        unsigned taps = 0;
+        for (int kh = 0; kh < map.ksize; ++kh)
+          if ((rows_ok >> kh) & 1u) taps |= cols_ok << (kh * map.ksize);
+        a_taps[i] = m < M ? taps : 0u;
+      } else {
+        a_off[i] = m < M ? static_cast<unsigned>((InRow(map, m) * K + chunk * 8) * 2) : kOutOfRange;
+        a_taps[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kWVecs; ++i) {
+      const int v = (i * 4 + wave) * 64 + lane;
+      const int row = v >> 3;
+      const int chunk = (v & 7) ^ ((row >> 1) & 7);
+      w_off[i] = static_cast<unsigned>(((n0 + row) * K + chunk * 8) * 2);  // N % BN == 0 (host checked)
+    }
+  }
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(X) - lead, 0, static_cast<int>(x_bytes + 2u * lead), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(W), 0, N * K * 2, 0x00020000);
+  // position of the NEXT K step to issue (steps are issued strictly in order)
+  int next_k0 = 0, next_c0 = 0, next_kh = 0, next_kw = 0, next_tap = 0;
+  auto issue_tile = [&](int stage) {
+    _Float16* base = lds + stage * kStageHalfs;
+    if constexpr (kSpatial) {
+      const int soff = ((next_kh * map.in_w + next_kw) * map.cin + next_c0) * 2;
+      const unsigned bit = 1u << next_tap;
+#pragma unroll
+      for (int i = 0; i < kAVecs; ++i)
+        DmaToLds(x_rsrc, (a_taps[i] & bit) ? a_off[i] : kOutOfRange, soff, base + (i * 4 + wave) * 512);
+      next_c0 += kBK;
+      if (next_c0 == map.cin) {
+        next_c0 = 0;
+        ++next_tap;
+        if (++next_kw == map.ksize) {
+          next_kw = 0;
+          ++next_kh;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kAVecs; ++i) DmaToLds(x_rsrc, a_off[i], next_k0 * 2, base + (i * 4 + wave) * 512);
+    }
+#pragma unroll
+    for (int i = 0; i < kWVecs; ++i) DmaToLds(w_rsrc, w_off[i], next_k0 * 2, base + BM * kBK + (i * 4 + wave) * 512);
+    next_k0 += kBK;
+  };
+
+  // ---- register staging (global -> VGPR -> LDS): the A/B alternative ---------------
+  // vector v -> (row v/8, chunk v%8), stored swizzled
   const _Float16* a_src[kAVecs];  // 1x1: fixed row pointer; spatial: image base (+ chunk)
   int a_dst[kAVecs];
   int a_ih0[kAVecs], a_iw0[kAVecs];  // spatial only: top-left input coordinate of the output pixel
-#pragma unroll
-  for (int i = 0; i < kAVecs; ++i) {
-    const int v = tid + i * kThreads;
-    const int row = v >> 3, chunk = v & 7;
-    const int m = m0 + row;
-    a_dst[i] = row * kBK + Swz(row, chunk) * 8;
-    if constexpr (kSpatial) {
-      const int img = m / map.ohw;
-      const int rem = m - img * map.ohw;
-      const int oh = rem / map.ow;
-      const int ow = rem - oh * map.ow;
-      a_src[i] = (m < M) ? X + static_cast<long long>(img) * map.in_h * map.in_w * map.cin + chunk * 8 : nullptr;
-      a_ih0[i] = oh * map.stride - map.pad;
-      a_iw0[i] = ow * map.stride - map.pad;
-    } else {
-      a_src[i] = (m < M) ? X + InRow(map, m) * K + chunk * 8 : nullptr;
-      a_ih0[i] = a_iw0[i] = 0;
-    }
-  }
-  const int ctiles = kSpatial ? map.cin / kBK : 1;  // K steps per tap
   const _Float16* w_src[kWVecs];
   int w_dst[kWVecs];
+  const int ctiles = kSpatial ? map.cin / kBK : 1;  // K steps per tap
+  if constexpr (!kGlds) {
 #pragma unroll
-  for (int i = 0; i < kWVecs; ++i) {
-    const int v = tid + i * kThreads;
-    const int row = v >> 3, chunk = v & 7;
-    w_src[i] = W + static_cast<long long>(n0 + row) * K + chunk * 8;  // N % BN == 0 (host checked)
-    w_dst[i] = BM * kBK + row * kBK + Swz(row, chunk) * 8;
+    for (int i = 0; i < kAVecs; ++i) {
+      const int v = tid + i * kThreads;
+      const int row = v >> 3;
+      const int chunk = v & 7;
+      const int m = m0 + row;
+      a_dst[i] = row * kBK + Swz(row, chunk) * 8;
+      if constexpr (kSpatial) {
+        const int img = m / map.ohw;
+        const int rem = m - img * map.ohw;
+        const int oh = rem / map.ow;
+        const int ow = rem - oh * map.ow;
+        a_src[i] = (m < M) ? X + static_cast<long long>(img) * map.in_h * map.in_w * map.cin + chunk * 8 : nullptr;
+        a_ih0[i] = oh * map.stride - map.pad;
+        a_iw0[i] = ow * map.stride - map.pad;
+      } else {
+        a_src[i] = (m < M) ? X + InRow(map, m) * K + chunk * 8 : nullptr;
+        a_ih0[i] = a_iw0[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kWVecs; ++i) {
+      const int v = tid + i * kThreads;
+      const int row = v >> 3;
+      const int chunk = v & 7;
+      w_src[i] = W + static_cast<long long>(n0 + row) * K + chunk * 8;  // N % BN == 0 (host checked)
+      w_dst[i] = BM * kBK + row * kBK + Swz(row, chunk) * 8;
+    }
   }
 
   half8 a_reg[kAVecs], w_reg[kWVecs];
@@ -176,39 +285,65 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
     for (int mi = 0; mi < kMI; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
 
   const int ktiles = K / kBK;
-  const int stages = ktiles > 1 ? 2 : 1;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  // fragment addressing: lane -> (row lane&15, 16-byte chunk lane>>4 [+4 for the second
+  // half of the K step]); the row swizzle only depends on lane&15 because every
+  // fragment starts at a multiple of 16 rows, and "+4 chunks" is an XOR of 32 halfs
   const int frag_row = lane & 15;
-  const int frag_chunk = lane >> 4;
-  for (int kt = 0; kt < ktiles; ++kt) {
-    const bool more = kt + 1 < ktiles;
-    if (more) load_tile(kt + 1);  // in flight while the MFMAs below run
-    const _Float16* xs = lds + (stages == 2 ? (kt & 1) : 0) * kStageHalfs;
-    const _Float16* ws = xs + BM * kBK;
+  const int frag_chunk = (lane >> 4) ^ ((frag_row >> 1) & 7);
+  const int xf_off = (wm * (BM / 2) + frag_row) * kBK + frag_chunk * 8;
+  const int wf_off = BM * kBK + (wn * (BN / 2) + frag_row) * kBK + frag_chunk * 8;
+  auto compute_tile = [&](int stage) {
+    const _Float16* base = lds + stage * kStageHalfs;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      const _Float16* xs = base + (xf_off ^ (kk * 32));
+      const _Float16* ws = base + (wf_off ^ (kk * 32));
       half8 xf[kMI], wf[kNI];
 #pragma unroll
-      for (int mi = 0; mi < kMI; ++mi) {
-        const int row = wm * (BM / 2) + mi * 16 + frag_row;
-        xf[mi] = *reinterpret_cast<const half8*>(xs + row * kBK + Swz(row, kk * 4 + frag_chunk) * 8);
-      }
+      for (int mi = 0; mi < kMI; ++mi) xf[mi] = *reinterpret_cast<const half8*>(xs + mi * 16 * kBK);
 #pragma unroll
-      for (int ni = 0; ni < kNI; ++ni) {
-        const int row = wn * (BN / 2) + ni * 16 + frag_row;
-        wf[ni] = *reinterpret_cast<const half8*>(ws + row * kBK + Swz(row, kk * 4 + frag_chunk) * 8);
-      }
+      for (int ni = 0; ni < kNI; ++ni) wf[ni] = *reinterpret_cast<const half8*>(ws + ni * 16 * kBK);
 #pragma unroll
       for (int ni = 0; ni < kNI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < kMI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
     }
-    if (more) {
-      store_tile((kt + 1) & 1);  // the other stage: last read one iteration ago, behind a barrier
-      __syncthreads();
+  };
+
+  if constexpr (kGlds) {
+    // `stages` LDS stages, the DMA runs stages-1 K steps ahead.  Per step: wait until
+    // THIS step's DMA has landed (with three stages a counted vmcnt leaves the next
+    // step's loads in flight), one raw barrier (a plain __syncthreads() would drain the
+    // DMA queue), then refill the stage every wave finished reading one step ago.
+    constexpr int kPerTile = kAVecs + kWVecs;  // DMA instructions a thread issues per K step
+    const int ahead = stages > 1 ? stages - 1 : 1;
+    for (int p = 0; p < ahead && p < ktiles; ++p) issue_tile(p);
+    int stage = 0;
+    int refill = stages > 1 ? ahead : 0;
+    for (int kt = 0; kt < ktiles; ++kt) {
+      if (ahead == 2 && kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerTile) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + ahead < ktiles) {
+        issue_tile(refill);
+        refill = refill + 1 == stages ? 0 : refill + 1;
+      }
+      compute_tile(stage);
+      stage = stage + 1 == stages ? 0 : stage + 1;
+    }
+  } else {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const bool more = kt + 1 < ktiles;
+      if (more) load_tile(kt + 1);  // in flight while the MFMAs below run
+      compute_tile(stages == 2 ? (kt & 1) : 0);
+      if (more) {
+        store_tile((kt + 1) & 1);  // the other stage: last read one iteration ago, behind a barrier
+        __syncthreads();
+      }
     }
   }
   __syncthreads();  // every wave is done reading the operand stages: reuse them for the output tile
@@ -287,19 +422,27 @@ __global__ __launch_bounds__(kThreads) void BiasActKernel(_Float16* __restrict__
   }
 }
 
-template <int BM, int BN, bool kSpatial>
+template <int BM, int BN, bool kSpatial, bool kGlds>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
-                  int M, int N, int K, int relu, const RowMap& map, hipStream_t st) {
+                  int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = N / BN;
   const int blocks = tiles_m * tiles_n;
   const int xcd_chunk = (blocks % 8 == 0) ? blocks / 8 : 0;  // the remap must be a bijection
-  const int stages = (K / kBK) > 1 ? 2 : 1;
+  const int ktiles = K / kBK;
+  if (!kGlds) stages = 2;
+  if (stages > ktiles) stages = ktiles;
   size_t lds_bytes = static_cast<size_t>(stages) * (BM + BN) * kBK * sizeof(_Float16);
   const size_t c_bytes = static_cast<size_t>(BM) * (BN + 8) * sizeof(_Float16);
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
-  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kSpatial>), dim3(blocks), dim3(kThreads), lds_bytes, st, x, w, bias, residual, y, M,
-                     N, K, relu, map, tiles_n, xcd_chunk);
+  if (lds_bytes > 64 * 1024) {
+    // above the default dynamic-LDS limit: raise it once per kernel instantiation
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kSpatial, kGlds>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
+  }
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kSpatial, kGlds>), dim3(blocks), dim3(kThreads), lds_bytes, st, x, w, bias, residual, y, M,
+                     N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
 }
@@ -310,7 +453,8 @@ extern "C" {
 
 // x: [batch,in_h,in_w,cin] fp16, w: [cout][ksize][ksize][cin] fp16 (the memory of
 // a channels-last [cout,cin,ksize,ksize] weight), y: [batch,oh,ow,cout].
-// variant: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile.
+// variant: low 4 bits 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile;
+// bit 4 selects register staging; bits 5-6 the number of LDS stages (2 or 3).
 int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                          int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu, int variant,
                          void* stream) {
@@ -335,34 +479,54 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
   map.pad = pad;
   map.ksize = ksize;
   map.cin = cin;
+  int staging = (variant >> 4) & 1;  // bit 4: register staging instead of the LDS DMA
+  int stages = (variant >> 5) & 3;   // bits 5-6: LDS stages of the DMA pipeline (2 or 3), 0 = auto
+  variant &= 15;
+  // the DMA path addresses activations with 32-bit byte offsets below kOutOfRange, and
+  // keeps one validity bit per tap in a 32-bit mask
+  const long long x_bytes_ll = static_cast<long long>(batch) * in_h * in_w * cin * 2;
+  const long long lead_bytes = (static_cast<long long>(pad) * in_w + pad) * cin * 2;
+  if (x_bytes_ll + lead_bytes >= 0x7FFFFFFFll || k_ll * cout * 2 >= 0x7FFFFFFFll || ksize * ksize > 32) staging = 1;
+  const unsigned x_bytes = staging ? 0u : static_cast<unsigned>(x_bytes_ll);
   if (variant == 0) {
-    // enough blocks to fill 256 CUs several times over first, then the bigger
-    // tile (more reuse per staged byte); thresholds from per-layer timings
+    // thresholds from per-layer timings (tools/conv_bench.py): a long K loop with
+    // enough 128x128 tiles to cover the chip is compute-bound and wants the most
+    // reuse per staged byte; otherwise enough blocks to fill 256 CUs several times
+    // over first, then the bigger tile
+    const long long blocks128 = static_cast<long long>((M + 127) / 128) * (cout / 128);
     const long long blocks64 = static_cast<long long>((M + 63) / 64) * (cout / 64);
-    const long long blocks128x64 = static_cast<long long>((M + 127) / 128) * (cout / 64);
-    variant = blocks64 <= 2048 ? 3 : ((blocks128x64 <= 8192 || cout % 128 != 0) ? 2 : 1);
+    if (cout % 128 == 0 && K >= 512 && blocks128 >= 256) variant = 1;
+    else variant = blocks64 <= 2048 ? 3 : 2;
   }
   if (variant == 1 && cout % 128 != 0) return -2;
+  if (stages != 2 && stages != 3) {
+    // a third stage hides more DMA latency but costs LDS: take it only when the grid is
+    // too small for the LDS limit on resident blocks to bind
+    const int bm = variant == 3 ? 64 : 128, bn = variant == 1 ? 128 : 64;
+    const long long blocks = static_cast<long long>((M + bm - 1) / bm) * (cout / bn);
+    const long long per_cu_wanted = (blocks + 255) / 256;
+    const long long per_cu_with_3 = (160 * 1024) / (3 * (bm + bn) * kBK * 2);
+    stages = per_cu_wanted <= per_cu_with_3 ? 3 : 2;
+  }
   auto st = static_cast<hipStream_t>(stream);
   auto xp = static_cast<const _Float16*>(x);
   auto wp = static_cast<const _Float16*>(w);
   auto bp = static_cast<const _Float16*>(bias);
   auto rp = static_cast<const _Float16*>(residual);
   auto yp = static_cast<_Float16*>(y);
-  if (spatial) {
-    switch (variant) {
-      case 1: return LaunchConvGemm<128, 128, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
-      case 2: return LaunchConvGemm<128, 64, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
-      case 3: return LaunchConvGemm<64, 64, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
-      default: return -3;
-    }
-  }
+  // staging: direct-to-LDS DMA by default; `staging` = 1 keeps the register-staged path (A/B testing)
+#define TCA_DISPATCH(BM_, BN_)                                                                                      \
+  (spatial ? (staging ? LaunchConvGemm<BM_, BN_, true, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)       \
+                      : LaunchConvGemm<BM_, BN_, true, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st))       \
+           : (staging ? LaunchConvGemm<BM_, BN_, false, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)      \
+                      : LaunchConvGemm<BM_, BN_, false, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)))
   switch (variant) {
-    case 1: return LaunchConvGemm<128, 128, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
-    case 2: return LaunchConvGemm<128, 64, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
-    case 3: return LaunchConvGemm<64, 64, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, st);
+    case 1: return TCA_DISPATCH(128, 128);
+    case 2: return TCA_DISPATCH(128, 64);
+    case 3: return TCA_DISPATCH(64, 64);
     default: return -3;
   }
+#undef TCA_DISPATCH
 }
 
 int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,

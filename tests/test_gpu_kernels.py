@@ -255,10 +255,11 @@ def test_conv1x1_exact_integer_operand_maps(torch):
     wt = torch.randint(-2, 3, (cout, cin), device="cuda").half()
     wt[5, 7] = 9.0
     bias = torch.arange(cout, device="cuda").half()
-    for variant in ("128x128", "128x64", "64x64"):
-        got = conv.conv1x1(x, wt, bias, None, relu=False, variant=variant)
-        ref = torch.nn.functional.conv2d(x.float(), wt.float().reshape(cout, cin, 1, 1), bias.float())
-        assert torch.equal(got.float(), ref), variant
+    for staging in ("lds2", "lds3", "reg"):
+        for variant in ("128x128", "128x64", "64x64"):
+            got = conv.conv1x1(x, wt, bias, None, relu=False, variant=variant, staging=staging)
+            ref = torch.nn.functional.conv2d(x.float(), wt.float().reshape(cout, cin, 1, 1), bias.float())
+            assert torch.equal(got.float(), ref), (variant, staging)
 
 
 @pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (True, False)])
@@ -310,9 +311,20 @@ def test_conv3x3_exact_integer_taps(torch):
     x = _nhwc(torch.randint(-2, 3, (2, 64, 9, 11), device="cuda").half())
     wt = _nhwc(torch.randint(-1, 2, (64, 64, 3, 3), device="cuda").half())
     wt[3, 5, 0, 2] = 4.0  # asymmetric in (kh, kw)
-    got = conv.conv2d(x, wt, None, None, relu=False, stride=1, padding=1, variant="64x64")
     ref = torch.nn.functional.conv2d(x.float(), wt.float(), None, stride=1, padding=1)
-    assert torch.equal(got.float(), ref)
+    for staging in ("lds2", "lds3", "reg"):
+        for variant in ("128x64", "64x64"):
+            got = conv.conv2d(x, wt, None, None, relu=False, stride=1, padding=1, variant=variant, staging=staging)
+            assert torch.equal(got.float(), ref), (variant, staging)
+    # stride 2, two K steps per tap, 128 output channels
+    x = _nhwc(torch.randint(-2, 3, (3, 128, 10, 7), device="cuda").half())
+    wt = _nhwc(torch.randint(-1, 2, (128, 128, 3, 3), device="cuda").half())
+    wt[7, 70, 2, 0] = 3.0
+    ref = torch.nn.functional.conv2d(x.float(), wt.float(), None, stride=2, padding=1)
+    for staging in ("lds2", "lds3", "reg"):
+        for variant in ("128x128", "128x64", "64x64"):
+            got = conv.conv2d(x, wt, None, None, relu=False, stride=2, padding=1, variant=variant, staging=staging)
+            assert torch.equal(got.float(), ref), (variant, staging)
 
 
 def test_batched_copy_many_entries_and_alignments(torch):

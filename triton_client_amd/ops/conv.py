@@ -19,6 +19,23 @@ from __future__ import annotations
 from ._device import check, lib
 
 VARIANTS = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3}
+# operand staging of the GEMM kernel: "lds" = direct global->LDS DMA (default),
+# "reg" = through registers + ds_write (kept for A/B measurements)
+_REG_STAGING = 16
+
+
+def _variant_code(variant, staging=None):
+    """Kernel selector word: tile variant, staging ("lds" | "lds2" | "lds3" pin the
+    number of LDS stages of the DMA pipeline, "reg" = register staging)."""
+    import os
+
+    code = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    staging = staging or os.environ.get("TCA_CONV_STAGING", "lds")
+    if staging not in ("lds", "lds2", "lds3", "reg"):
+        raise ValueError("staging must be 'lds', 'lds2', 'lds3' or 'reg'")
+    if staging == "reg":
+        return code | _REG_STAGING
+    return code | (int(staging[3:]) << 5 if len(staging) > 3 else 0)
 
 
 def gemm_pays(pixels, cout, k_total):
@@ -44,7 +61,7 @@ def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
 
-def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0, out=None):
+def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0, out=None, staging=None):
     """``act(conv1x1(x, weight) + bias (+ residual))``.
 
     x        fp16 ``[N, Cin, H, W]`` channels-last
@@ -74,7 +91,7 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0
         raise ValueError("residual must match the output (fp16, channels-last)")
     if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
-    code = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    code = _variant_code(variant, staging)
     rc = lib().tca_conv1x1_launch(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
                                   residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w,
                                   int(stride), cin, cout, 1 if relu else 0, code, _stream())
@@ -82,7 +99,8 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0
     return out
 
 
-def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0, variant=0, out=None):
+def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0, variant=0, out=None,
+           staging=None):
     """``act(conv2d(x, weight) + bias (+ residual))`` as an implicit GEMM on the
     MFMA kernel (square kernels, e.g. 3x3 with padding 1).
 
@@ -114,7 +132,7 @@ def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0,
         raise ValueError("residual must match the output (fp16, channels-last)")
     if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
-    code = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    code = _variant_code(variant, staging)
     rc = lib().tca_conv_gemm_launch(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
                                     residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, r,
                                     int(stride), int(padding), cin, cout, 1 if relu else 0, code, _stream())
