@@ -20,6 +20,7 @@
 //                   in-place pass for convolutions a library computed (3x3,
 //                   7x7): one pass instead of bias-add, residual-add and ReLU
 //                   passes.
+//   BiasReluMaxPoolKernel  the stem's epilogue folded into its 3x3/2 max pooling.
 //
 // GEMM structure: 256 threads = 4 wavefronts (2x2), block tile BM x BN, K step
 // 64, v_mfma_f32_16x16x32_f16.  The weight tile is the MFMA A operand and the
@@ -422,6 +423,52 @@ __global__ __launch_bounds__(kThreads) void BiasActKernel(_Float16* __restrict__
   }
 }
 
+// out[n][oh][ow][c] = relu(max over the 3x3 stride-2 pad-1 window of in[n][.][.][c] + bias[c]).
+// Adding the bias and ReLU commute with the window maximum (both are monotonic), so
+// the stem's activation is read ONCE at full resolution and only the pooled quarter
+// is written - instead of an epilogue pass (read + write) followed by the pooling
+// pass.  One thread per output pixel and 8 channels; 16-byte accesses; the
+// overlapping window columns of neighbouring threads hit in L1/L2.
+__global__ __launch_bounds__(kThreads) void BiasReluMaxPoolKernel(const _Float16* __restrict__ x,
+                                                                  const _Float16* __restrict__ bias,
+                                                                  _Float16* __restrict__ y, int in_h, int in_w,
+                                                                  int out_h, int out_w, int channel_vecs,
+                                                                  long long out_vecs) {
+  const long long stride = static_cast<long long>(gridDim.x) * kThreads;
+  for (long long v = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x; v < out_vecs; v += stride) {
+    const int cv = static_cast<int>(v % channel_vecs);
+    long long pix = v / channel_vecs;
+    const int ow = static_cast<int>(pix % out_w);
+    pix /= out_w;
+    const int oh = static_cast<int>(pix % out_h);
+    const long long img = pix / out_h;
+    const _Float16* base = x + (img * in_h * in_w) * channel_vecs * 8 + cv * 8;
+    half8 best;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) best[j] = static_cast<_Float16>(-65504.f);
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int ih = oh * 2 - 1 + dh;
+      if (static_cast<unsigned>(ih) >= static_cast<unsigned>(in_h)) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int iw = ow * 2 - 1 + dw;
+        if (static_cast<unsigned>(iw) >= static_cast<unsigned>(in_w)) continue;
+        const half8 val = *reinterpret_cast<const half8*>(base + (static_cast<long long>(ih) * in_w + iw) * channel_vecs * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[j] = val[j] > best[j] ? val[j] : best[j];
+      }
+    }
+    const half8 b = *reinterpret_cast<const half8*>(bias + cv * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = static_cast<float>(best[j]) + static_cast<float>(b[j]);
+      best[j] = static_cast<_Float16>(f > 0.f ? f : 0.f);
+    }
+    *reinterpret_cast<half8*>(y + v * 8) = best;
+  }
+}
+
 template <int BM, int BN, bool kSpatial, bool kGlds>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, hipStream_t st) {
@@ -545,6 +592,23 @@ int tca_bias_act_launch(void* y, const void* bias, const void* residual, long lo
   hipLaunchKernelGGL(BiasActKernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream), static_cast<_Float16*>(y), static_cast<const _Float16*>(bias),
                      static_cast<const _Float16*>(residual), vecs, channels / 8, relu);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
+}
+
+int tca_bias_relu_maxpool_launch(const void* x, const void* bias, void* y, int batch, int in_h, int in_w, int channels,
+                                 void* stream) {
+  if (!x || !bias || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || channels <= 0) return -1;
+  if (channels % 8 != 0) return -2;
+  const int out_h = (in_h - 1) / 2 + 1;  // (H + 2*1 - 3) / 2 + 1
+  const int out_w = (in_w - 1) / 2 + 1;
+  const long long out_vecs = static_cast<long long>(batch) * out_h * out_w * (channels / 8);
+  long long blocks = (out_vecs + kThreads - 1) / kThreads;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(BiasReluMaxPoolKernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const _Float16*>(x),
+                     static_cast<const _Float16*>(bias), static_cast<_Float16*>(y), in_h, in_w, out_h, out_w,
+                     channels / 8, out_vecs);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
 }

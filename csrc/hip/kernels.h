@@ -80,4 +80,8 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
 int tca_batched_copy_launch(const void* const* srcs, void* const* dsts, const uint64_t* bytes, int n, void* stream);
 int tca_bias_act_launch(void* y, const void* bias, const void* residual, long long rows, int channels, int relu,
                         void* stream);
+
+// y[batch][oh][ow][channels] = relu(maxpool3x3/2/pad1(x[batch][in_h][in_w][channels]) + bias), fp16 NHWC, channels % 8 == 0.
+int tca_bias_relu_maxpool_launch(const void* x, const void* bias, void* y, int batch, int in_h, int in_w, int channels,
+                                 void* stream);
 }

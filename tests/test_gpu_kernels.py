@@ -346,3 +346,19 @@ def test_batched_copy_many_entries_and_alignments(torch):
         assert int(dst[i, n:].sum()) == 0 and int(dst[i, :shift].sum()) == 0
     assert int(dst[150:].sum()) == 0
     batched_copy([])  # no-op
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 64, 112, 112), (3, 16, 9, 7), (1, 8, 1, 1), (2, 24, 10, 13)])
+def test_bias_relu_maxpool_matches_reference(torch, shape):
+    from triton_client_amd.ops import conv
+
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = _nhwc(torch.randn(*shape, device="cuda", generator=gen).half())
+    bias = torch.randn(shape[1], device="cuda", generator=gen).half()
+    got = conv.bias_relu_maxpool(x, bias)
+    # the kernel adds the bias to the pooled maximum in fp32 and rounds once
+    pooled = torch.nn.functional.max_pool2d(x.float(), 3, stride=2, padding=1)
+    ref = (pooled + bias.float().view(1, -1, 1, 1)).clamp_min(0).half()
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, ref)

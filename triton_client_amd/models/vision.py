@@ -283,8 +283,9 @@ class ResNet50(Model):
             return conv.bias_act_(F.conv2d(t, w4, None, stride=stride, padding=pad), bias, None, True)
 
         stem, blocks = self._plan
-        y = spatial(x, stem)  # Cin = 3: library kernel + fused epilogue
-        y = F.max_pool2d(y, 3, stride=2, padding=1)
+        # Cin = 3: library kernel; its bias + ReLU ride in the pooling pass
+        w4, bias, stride, pad = stem
+        y = conv.bias_relu_maxpool(F.conv2d(x, w4, None, stride=stride, padding=pad), bias)
         for a, mid, c, down in blocks:
             identity = y if down is None else pointwise(y, down, None, False)
             t = pointwise(y, a, None, True)

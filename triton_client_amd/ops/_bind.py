@@ -85,6 +85,8 @@ def install(lib):
     lib.tca_batched_copy_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p]
     lib.tca_bias_act_launch.restype = c_int
     lib.tca_bias_act_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]
+    lib.tca_bias_relu_maxpool_launch.restype = c_int
+    lib.tca_bias_relu_maxpool_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     install_rt(lib)
 
 

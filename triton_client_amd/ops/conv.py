@@ -6,6 +6,7 @@
 ``bias_act_`` the same epilogue as ONE in-place pass for convolutions computed
               by a library (3x3 / 7x7): replaces the separate bias-add,
               residual-add and ReLU passes of an eager forward.
+``bias_relu_maxpool``  the stem's bias + ReLU folded into its 3x3/2 max pooling.
 
 Tensors are torch CUDA tensors in channels-last memory format, i.e. logical
 ``[N, C, H, W]`` with strides of a ``[N, H, W, C]`` array.  The reference has no
@@ -156,3 +157,26 @@ def bias_act_(y, bias, residual=None, relu=False):
                                    n * h * w, c, 1 if relu else 0, _stream())
     check(rc, "tca_bias_act_launch")
     return y
+
+
+def bias_relu_maxpool(x, bias, out=None):
+    """``max_pool2d(relu(x + bias), 3, stride=2, padding=1)`` in one pass over a
+    channels-last fp16 tensor (bias and ReLU commute with the window maximum, so
+    they are applied to the pooled values)."""
+    import torch
+
+    if x.dtype != torch.float16 or not _is_nhwc(x):
+        raise ValueError("x must be a channels-last fp16 [N, C, H, W] tensor")
+    n, c, h, w = x.shape
+    if c % 8 != 0:
+        raise ValueError("C must be a multiple of 8")
+    if bias.numel() != c or bias.dtype != torch.float16 or not bias.is_contiguous():
+        raise ValueError("bias must be a contiguous fp16 vector of C elements")
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((n, c, oh, ow), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    elif tuple(out.shape) != (n, c, oh, ow) or out.dtype != torch.float16 or not _is_nhwc(out):
+        raise ValueError("out must be a channels-last fp16 tensor of the pooled shape")
+    rc = lib().tca_bias_relu_maxpool_launch(x.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w, c, _stream())
+    check(rc, "tca_bias_relu_maxpool_launch")
+    return out
