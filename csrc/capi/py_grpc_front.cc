@@ -50,12 +50,33 @@ void CallPython(PyObject* fn, const char* fmt, ...) {
   PyGILState_Release(gil);
 }
 
-int FrontInit(PyObject* self_obj, PyObject* args, PyObject*) {
+int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   auto* self = reinterpret_cast<PyGrpcFront*>(self_obj);
   const char* host = nullptr;
   int port = 0, threads = 2;
   PyObject *on_unary, *on_msg, *on_end, *on_cancel;
-  if (!PyArg_ParseTuple(args, "siiOOOO", &host, &port, &threads, &on_unary, &on_msg, &on_end, &on_cancel)) return -1;
+  // optional TLS: server certificate chain + key (PEM files); client_ca makes client certificates mandatory
+  const char *tls_cert = nullptr, *tls_key = nullptr, *tls_client_ca = nullptr;
+  static const char* kwlist[] = {"host", "port", "threads", "on_unary", "on_stream_message", "on_stream_end",
+                                 "on_cancel", "tls_cert", "tls_key", "tls_client_ca", nullptr};
+  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "siiOOOO|zzz", const_cast<char**>(kwlist), &host, &port, &threads,
+                                   &on_unary, &on_msg, &on_end, &on_cancel, &tls_cert, &tls_key, &tls_client_ca))
+    return -1;
+  std::shared_ptr<tca::net::TlsContext> tls;
+  if (tls_cert != nullptr || tls_key != nullptr) {
+    tca::net::TlsOptions opt;
+    opt.server = true;
+    opt.cert_file = tls_cert ? tls_cert : "";
+    opt.key_file = tls_key ? tls_key : "";
+    opt.ca_file = tls_client_ca ? tls_client_ca : "";
+    opt.verify_peer = tls_client_ca != nullptr;
+    opt.alpn = {"h2"};
+    const tca::Error e = tca::net::TlsContext::Create(opt, &tls);
+    if (!e.IsOk()) {
+      PyErr_SetString(PyExc_ValueError, e.Message().c_str());
+      return -1;
+    }
+  }
   Py_INCREF(on_unary);
   Py_INCREF(on_msg);
   Py_INCREF(on_end);
@@ -78,6 +99,7 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject*) {
   };
   h.on_cancel = [self](uint64_t call) { CallPython(self->on_cancel, "(K)", static_cast<unsigned long long>(call)); };
   self->front = new tca::server::GrpcServerFront(host, port, threads, {"ModelStreamInfer"}, std::move(h));
+  if (tls) self->front->SetTls(std::move(tls));
   return 0;
 }
 

@@ -1,5 +1,8 @@
 // Shared helpers of the C++ examples: flag parsing (-v, -u URL, -H 'K:V', -t
-// client timeout in microseconds) and error handling.
+// client timeout in microseconds, the TLS flags of the reference's
+// simple_http_infer_client / simple_grpc_infer_client) and error handling.
+//   HTTP:  -u https://host:port  --verify-peer 0|1  --verify-host 0|2  --ca-certs FILE  --cert-file FILE  --key-file FILE
+//   gRPC:  --ssl  --root-certificates FILE  --private-key FILE  --certificate-chain FILE
 #pragma once
 
 #include <cstdlib>
@@ -34,6 +37,9 @@ struct CommonFlags {
   std::string url = "localhost:8000";
   tc::Headers headers;
   uint64_t client_timeout_us = 0;
+  tc::HttpSslOptions http_ssl;
+  bool grpc_ssl = false;
+  tc::SslOptions grpc_ssl_options;
   std::vector<std::string> rest;  // unparsed arguments, in order
 };
 
@@ -51,6 +57,24 @@ inline CommonFlags ParseCommonFlags(int argc, char** argv) {
       const std::string h = argv[++i];
       const size_t colon = h.find(':');
       if (colon != std::string::npos) f.headers[h.substr(0, colon)] = h.substr(colon + 1);
+    } else if (a == "--verify-peer" && i + 1 < argc) {
+      f.http_ssl.verify_peer = std::atol(argv[++i]);
+    } else if (a == "--verify-host" && i + 1 < argc) {
+      f.http_ssl.verify_host = std::atol(argv[++i]);
+    } else if (a == "--ca-certs" && i + 1 < argc) {
+      f.http_ssl.ca_info = argv[++i];
+    } else if (a == "--cert-file" && i + 1 < argc) {
+      f.http_ssl.cert = argv[++i];
+    } else if (a == "--key-file" && i + 1 < argc) {
+      f.http_ssl.key = argv[++i];
+    } else if (a == "--ssl") {
+      f.grpc_ssl = true;
+    } else if (a == "--root-certificates" && i + 1 < argc) {
+      f.grpc_ssl_options.root_certificates = argv[++i];
+    } else if (a == "--private-key" && i + 1 < argc) {
+      f.grpc_ssl_options.private_key = argv[++i];
+    } else if (a == "--certificate-chain" && i + 1 < argc) {
+      f.grpc_ssl_options.certificate_chain = argv[++i];
     } else {
       f.rest.push_back(a);
     }
@@ -60,7 +84,7 @@ inline CommonFlags ParseCommonFlags(int argc, char** argv) {
 
 inline std::unique_ptr<tc::InferenceServerHttpClient> MakeClient(const CommonFlags& f) {
   std::unique_ptr<tc::InferenceServerHttpClient> client;
-  FAIL_IF_ERR(tc::InferenceServerHttpClient::Create(&client, f.url, f.verbose), "unable to create http client");
+  FAIL_IF_ERR(tc::InferenceServerHttpClient::Create(&client, f.url, f.verbose, f.http_ssl), "unable to create http client");
   return client;
 }
 
@@ -69,7 +93,7 @@ inline std::unique_ptr<tc::InferenceServerGrpcClient> MakeGrpcClient(
   std::unique_ptr<tc::InferenceServerGrpcClient> client;
   // -u defaults to the HTTP port: the gRPC examples move it to 8001
   const std::string url = f.url == "localhost:8000" ? "localhost:8001" : f.url;
-  FAIL_IF_ERR(tc::InferenceServerGrpcClient::Create(&client, url, f.verbose, false, tc::SslOptions(), keepalive, cached),
+  FAIL_IF_ERR(tc::InferenceServerGrpcClient::Create(&client, url, f.verbose, f.grpc_ssl, f.grpc_ssl_options, keepalive, cached),
               "unable to create grpc client");
   return client;
 }

@@ -68,7 +68,7 @@ int HttpToGrpc(int http_status) {
 }  // namespace
 
 Error GrpcChannel::Create(std::shared_ptr<GrpcChannel>* channel, const std::string& url, bool verbose,
-                          const KeepAliveOptions& keepalive) {
+                          const KeepAliveOptions& keepalive, std::shared_ptr<net::TlsContext> tls) {
   std::string u = url;
   const size_t scheme = u.find("://");
   if (scheme != std::string::npos) u = u.substr(scheme + 3);
@@ -83,12 +83,14 @@ Error GrpcChannel::Create(std::shared_ptr<GrpcChannel>* channel, const std::stri
     }
   }
   if (host.empty()) return Error("invalid gRPC url '" + url + "'");
-  channel->reset(new GrpcChannel(url, host, port, verbose, keepalive));
+  channel->reset(new GrpcChannel(url, host, port, verbose, keepalive, std::move(tls)));
   return Error::Success();
 }
 
-GrpcChannel::GrpcChannel(std::string url, std::string host, int port, bool verbose, const KeepAliveOptions& keepalive)
-    : url_(std::move(url)), host_(std::move(host)), port_(port), verbose_(verbose), keepalive_(keepalive) {
+GrpcChannel::GrpcChannel(std::string url, std::string host, int port, bool verbose, const KeepAliveOptions& keepalive,
+                         std::shared_ptr<net::TlsContext> tls)
+    : url_(std::move(url)), host_(std::move(host)), port_(port), verbose_(verbose), keepalive_(keepalive),
+      tls_context_(std::move(tls)) {
   epfd_ = epoll_create1(EPOLL_CLOEXEC);
   wake_fd_ = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);
   epoll_event ev{};
@@ -103,6 +105,7 @@ GrpcChannel::~GrpcChannel() {
   const uint64_t one = 1;
   if (write(wake_fd_, &one, sizeof(one)) < 0) { /* the loop also polls stop_ on its timeout */ }
   if (thread_.joinable()) thread_.join();
+  tls_.reset();
   if (fd_ >= 0) close(fd_);
   close(wake_fd_);
   close(epfd_);
@@ -171,6 +174,19 @@ bool GrpcChannel::EnsureConnected(std::string* why) {
   const int buf = 4 << 20;
   setsockopt(fd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof(buf));
   setsockopt(fd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof(buf));
+  if (tls_context_) {
+    // the connect above already waits on this thread; the handshake does the same
+    std::unique_ptr<net::TlsSession> session(new net::TlsSession(tls_context_, host_, fd));
+    Error e = net::HandshakeBlocking(session.get(), fd, 5000);
+    if (e.IsOk() && session->Alpn() != "h2") e = Error("the server did not agree to HTTP/2 (ALPN '" + session->Alpn() + "')");
+    if (!e.IsOk()) {
+      session.reset();
+      close(fd);
+      *why = "failed to connect to " + host_ + ":" + std::to_string(port_) + ": " + e.Message();
+      return false;
+    }
+    tls_ = std::move(session);
+  }
   fd_ = fd;
   h2::Connection::Callbacks cb;
   cb.on_headers = [this](uint32_t s, h2::HeaderList&& h, bool end) { OnHeaders(s, std::move(h), end); };
@@ -202,6 +218,7 @@ bool GrpcChannel::EnsureConnected(std::string* why) {
 }
 
 void GrpcChannel::Disconnect(const std::string& why) {
+  tls_.reset();
   if (fd_ >= 0) {
     epoll_ctl(epfd_, EPOLL_CTL_DEL, fd_, nullptr);
     close(fd_);
@@ -249,7 +266,7 @@ void GrpcChannel::OpenCallStream(uint64_t id, Call* call) {
   }
   h2::HeaderList h;
   h.push_back({":method", "POST"});
-  h.push_back({":scheme", "http"});
+  h.push_back({":scheme", tls_context_ ? "https" : "http"});
   h.push_back({":path", "/inference.GRPCInferenceService/" + call->method});
   h.push_back({":authority", host_ + ":" + std::to_string(port_)});
   h.push_back({"te", "trailers"});
@@ -375,7 +392,18 @@ void GrpcChannel::WriteSocket() {
   while (conn_ && conn_->WantsWrite() && fd_ >= 0) {
     const std::string& out = conn_->Output();
     const size_t off = conn_->OutputOffset();
-    const ssize_t n = send(fd_, out.data() + off, out.size() - off, MSG_NOSIGNAL);
+    ssize_t n;
+    if (tls_) {
+      n = tls_->Write(out.data() + off, out.size() - off);
+      if (n == net::TlsSession::kWouldBlock) return;  // the edge-triggered loop calls again on the next event
+      if (n < 0) {
+        const std::string why = tls_->LastError();  // Disconnect() destroys the session that owns the text
+        Disconnect(why);
+        return;
+      }
+    } else {
+      n = send(fd_, out.data() + off, out.size() - off, MSG_NOSIGNAL);
+    }
     if (n > 0) {
       conn_->ConsumeOutput(static_cast<size_t>(n));
       last_activity_ns_ = NowNs();
@@ -393,7 +421,18 @@ void GrpcChannel::WriteSocket() {
 bool GrpcChannel::ReadSocket() {
   static thread_local std::vector<uint8_t> buf(256 * 1024);
   while (fd_ >= 0) {
-    const ssize_t n = recv(fd_, buf.data(), buf.size(), 0);
+    ssize_t n;
+    if (tls_) {
+      n = tls_->Read(buf.data(), buf.size());
+      if (n == net::TlsSession::kWouldBlock) return true;
+      if (n < 0) {
+        const std::string why = tls_->LastError();
+        Disconnect(why);
+        return false;
+      }
+    } else {
+      n = recv(fd_, buf.data(), buf.size(), 0);
+    }
     if (n > 0) {
       last_activity_ns_ = NowNs();
       const Error e = conn_->Receive(buf.data(), static_cast<size_t>(n));

@@ -492,31 +492,43 @@ InferenceServerGrpcClient::InferenceServerGrpcClient(std::shared_ptr<GrpcChannel
 InferenceServerGrpcClient::~InferenceServerGrpcClient() {
   exiting_.store(true);
   StopStream();
-  const std::string url = channel_->Url();
   channel_.reset();
   std::lock_guard<std::mutex> lk(g_cache_mu);
-  auto it = g_cache.find(url);
-  if (it != g_cache.end() && it->second.channel.expired()) g_cache.erase(it);
+  for (auto it = g_cache.begin(); it != g_cache.end();) {
+    if (it->second.channel.expired()) it = g_cache.erase(it);
+    else ++it;
+  }
 }
 
 Error InferenceServerGrpcClient::Create(std::unique_ptr<InferenceServerGrpcClient>* client, const std::string& server_url,
-                                        bool verbose, bool use_ssl, const SslOptions&,
+                                        bool verbose, bool use_ssl, const SslOptions& ssl_options,
                                         const KeepAliveOptions& keepalive_options, bool use_cached_channel) {
-  if (use_ssl) return Error("this build of the gRPC client has no TLS support");
+  std::shared_ptr<net::TlsContext> tls;
+  std::string cache_key = server_url;
+  if (use_ssl) {
+    net::TlsOptions opt;
+    opt.ca_file = ssl_options.root_certificates;
+    opt.key_file = ssl_options.private_key;
+    opt.cert_file = ssl_options.certificate_chain;
+    opt.alpn = {"h2"};
+    TCA_RETURN_IF_ERROR(net::TlsContext::Create(opt, &tls));
+    // a secure channel is only shared between clients created with the same credentials
+    cache_key += "|tls|" + opt.ca_file + "|" + opt.key_file + "|" + opt.cert_file;
+  }
   std::shared_ptr<GrpcChannel> channel;
   if (use_cached_channel) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    CacheEntry& entry = g_cache[server_url];
+    CacheEntry& entry = g_cache[cache_key];
     channel = entry.channel.lock();
     if (channel && entry.shares < MaxShareCount()) {
       ++entry.shares;
     } else {
-      TCA_RETURN_IF_ERROR(GrpcChannel::Create(&channel, server_url, verbose, keepalive_options));
+      TCA_RETURN_IF_ERROR(GrpcChannel::Create(&channel, server_url, verbose, keepalive_options, tls));
       entry.channel = channel;
       entry.shares = 1;
     }
   } else {
-    TCA_RETURN_IF_ERROR(GrpcChannel::Create(&channel, server_url, verbose, keepalive_options));
+    TCA_RETURN_IF_ERROR(GrpcChannel::Create(&channel, server_url, verbose, keepalive_options, tls));
   }
   client->reset(new InferenceServerGrpcClient(std::move(channel), verbose));
   return Error::Success();

@@ -77,6 +77,8 @@ struct GrpcServerFront::Reactor {
     std::map<uint32_t, StreamState> streams;
     bool want_write = false;  // EPOLLOUT armed
     bool dead = false;
+    std::unique_ptr<net::TlsSession> tls;  // null = cleartext
+    bool handshaking = false;
   };
   struct Command {
     enum Kind { SEND, FINISH, REPLY } kind;
@@ -129,9 +131,14 @@ struct GrpcServerFront::Reactor {
       ev.events = EPOLLIN | EPOLLRDHUP;
       ev.data.u64 = (1ull << 32) | c->id;
       epoll_ctl(epfd, EPOLL_CTL_ADD, fd, &ev);
+      if (owner->tls_) {
+        c->tls.reset(new net::TlsSession(owner->tls_, std::string(), fd));
+        c->handshaking = true;
+      }
       conns[c->id] = std::move(c);
       owner->accepted_.fetch_add(1);
-      Write(raw);
+      if (raw->handshaking) Handshake(raw);
+      else Write(raw);
     }
   }
 
@@ -289,21 +296,57 @@ struct GrpcServerFront::Reactor {
     Write(c);
   }
 
+  void ArmWrite(Conn* c, bool on) {
+    if (c->want_write == on) return;
+    epoll_event ev{};
+    ev.events = EPOLLIN | EPOLLRDHUP;
+    if (on) ev.events |= EPOLLOUT;
+    ev.data.u64 = (1ull << 32) | c->id;
+    epoll_ctl(epfd, EPOLL_CTL_MOD, c->fd, &ev);
+    c->want_write = on;
+  }
+
+  // false while the TLS handshake is still in progress (or failed: c->dead)
+  bool Handshake(Conn* c) {
+    const int rc = c->tls->Handshake();
+    if (rc == net::TlsSession::kWouldBlock) {
+      ArmWrite(c, c->tls->WantsWrite());
+      return false;
+    }
+    if (rc != 1 || c->tls->Alpn() != "h2") {
+      c->dead = true;
+      return false;
+    }
+    c->handshaking = false;
+    ArmWrite(c, false);
+    Write(c);  // the server SETTINGS queued at accept time
+    return !c->dead;
+  }
+
   void Write(Conn* c) {
+    if (c->handshaking) return;
     while (c->h2->WantsWrite()) {
       const std::string& out = c->h2->Output();
       const size_t off = c->h2->OutputOffset();
-      const ssize_t n = send(c->fd, out.data() + off, out.size() - off, MSG_NOSIGNAL);
+      ssize_t n;
+      if (c->tls) {
+        n = c->tls->Write(out.data() + off, out.size() - off);
+        if (n == net::TlsSession::kWouldBlock) {
+          // waiting for the socket to drain, or (renegotiation) for the peer: the read path calls Write again
+          ArmWrite(c, c->tls->WantsWrite());
+          return;
+        }
+        if (n < 0) {
+          c->dead = true;
+          return;
+        }
+      } else {
+        n = send(c->fd, out.data() + off, out.size() - off, MSG_NOSIGNAL);
+      }
       if (n > 0) {
         c->h2->ConsumeOutput(static_cast<size_t>(n));
       } else if (n < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) {
-        if (!c->want_write) {
-          epoll_event ev{};
-          ev.events = EPOLLIN | EPOLLOUT | EPOLLRDHUP;
-          ev.data.u64 = (1ull << 32) | c->id;
-          epoll_ctl(epfd, EPOLL_CTL_MOD, c->fd, &ev);
-          c->want_write = true;
-        }
+        ArmWrite(c, true);
         return;
       } else if (n < 0 && errno == EINTR) {
         continue;
@@ -312,19 +355,26 @@ struct GrpcServerFront::Reactor {
         return;
       }
     }
-    if (c->want_write) {
-      epoll_event ev{};
-      ev.events = EPOLLIN | EPOLLRDHUP;
-      ev.data.u64 = (1ull << 32) | c->id;
-      epoll_ctl(epfd, EPOLL_CTL_MOD, c->fd, &ev);
-      c->want_write = false;
-    }
+    ArmWrite(c, false);
   }
 
   void Read(Conn* c) {
     static thread_local std::vector<uint8_t> buf(512 * 1024);
-    for (int rounds = 0; rounds < 16 && !c->dead; ++rounds) {
-      const ssize_t n = recv(c->fd, buf.data(), buf.size(), 0);
+    if (c->handshaking && !Handshake(c)) return;
+    // a TLS read returns one record (<= 16 KiB) at a time: allow more rounds per wake-up
+    const int max_rounds = c->tls ? 64 : 16;
+    for (int rounds = 0; rounds < max_rounds && !c->dead; ++rounds) {
+      ssize_t n;
+      if (c->tls) {
+        n = c->tls->Read(buf.data(), buf.size());
+        if (n == net::TlsSession::kWouldBlock) break;
+        if (n < 0) {
+          c->dead = true;
+          break;
+        }
+      } else {
+        n = recv(c->fd, buf.data(), buf.size(), 0);
+      }
       if (n > 0) {
         const Error e = c->h2->Receive(buf.data(), static_cast<size_t>(n));
         if (!e.IsOk()) {
@@ -332,7 +382,7 @@ struct GrpcServerFront::Reactor {
           c->dead = true;
           return;
         }
-        if (static_cast<size_t>(n) < buf.size()) break;
+        if (!c->tls && static_cast<size_t>(n) < buf.size()) break;
       } else if (n == 0) {
         c->dead = true;
       } else if (errno == EAGAIN || errno == EWOULDBLOCK) {
@@ -349,6 +399,7 @@ struct GrpcServerFront::Reactor {
     for (const auto& kv : c->streams) open.push_back(kv.first);
     for (uint32_t s : open) Cancelled(c, s);
     epoll_ctl(epfd, EPOLL_CTL_DEL, c->fd, nullptr);
+    c->tls.reset();
     close(c->fd);
     conns.erase(c->id);
   }
@@ -369,7 +420,10 @@ struct GrpcServerFront::Reactor {
           if (it == conns.end()) continue;
           Conn* c = it->second.get();
           if (events[i].events & (EPOLLIN | EPOLLHUP | EPOLLRDHUP | EPOLLERR)) Read(c);
-          if (!c->dead && (events[i].events & EPOLLOUT)) Write(c);
+          if (!c->dead && (events[i].events & EPOLLOUT)) {
+            if (c->handshaking) Handshake(c);
+            else Write(c);
+          }
           if (c->dead) Close(c);
         }
       }

@@ -450,9 +450,21 @@ InferenceServerHttpClient::~InferenceServerHttpClient() {
 }
 
 Error InferenceServerHttpClient::Create(std::unique_ptr<InferenceServerHttpClient>* client, const std::string& server_url,
-                                        bool verbose, const HttpSslOptions&) {
+                                        bool verbose, const HttpSslOptions& ssl_options) {
   HttpEndpoint ep;
   TCA_RETURN_IF_ERROR(ParseHttpUrl(server_url, &ep));
+  if (ep.https) {
+    net::TlsOptions tls;
+    tls.verify_peer = ssl_options.verify_peer != 0;
+    tls.verify_host = ssl_options.verify_host != 0;
+    tls.ca_file = ssl_options.ca_info;
+    tls.cert_file = ssl_options.cert;
+    tls.cert_der = ssl_options.cert_type == HttpSslOptions::CERT_DER;
+    tls.key_file = ssl_options.key;
+    tls.key_der = ssl_options.key_type == HttpSslOptions::KEY_DER;
+    tls.alpn = {"http/1.1"};
+    TCA_RETURN_IF_ERROR(net::TlsContext::Create(tls, &ep.tls));
+  }
   client->reset(new InferenceServerHttpClient(ep, verbose));
   return Error::Success();
 }

@@ -43,16 +43,22 @@ std::string Trim(const std::string& s) {
 }  // namespace
 
 Error ParseHttpUrl(const std::string& url, HttpEndpoint* out) {
-  if (url.rfind("http://", 0) == 0 || url.rfind("https://", 0) == 0)
-    return Error("url should not include the scheme");
-  std::string hostport = url, base;
-  const size_t slash = url.find('/');
+  std::string rest = url;
+  out->https = false;
+  if (rest.rfind("https://", 0) == 0) {
+    out->https = true;
+    rest.erase(0, 8);
+  } else if (rest.rfind("http://", 0) == 0) {
+    rest.erase(0, 7);
+  }
+  std::string hostport = rest, base;
+  const size_t slash = rest.find('/');
   if (slash != std::string::npos) {
-    hostport = url.substr(0, slash);
-    base = url.substr(slash);
+    hostport = rest.substr(0, slash);
+    base = rest.substr(slash);
     while (!base.empty() && base.back() == '/') base.pop_back();
   }
-  std::string host = hostport, port = "80";
+  std::string host = hostport, port = out->https ? "443" : "80";
   if (!hostport.empty() && hostport[0] == '[') {
     const size_t close = hostport.find(']');
     if (close == std::string::npos) return Error("malformed IPv6 literal in url '" + url + "'");
@@ -75,6 +81,8 @@ Error ParseHttpUrl(const std::string& url, HttpEndpoint* out) {
 
 //==============================================================================
 void HttpConn::Close() {
+  tls_.reset();  // before the socket: the session may still write its close_notify
+  tls_blocked_ = false;
   if (fd_ >= 0) {
     ::close(fd_);
     fd_ = -1;
@@ -129,7 +137,7 @@ void HttpConn::BuildHead() {
   head_ += spec_->target;
   head_ += " HTTP/1.1\r\nHost: ";
   head_ += ep_.host;
-  if (ep_.port != 80) {
+  if (ep_.port != (ep_.https ? 443 : 80)) {
     head_ += ':';
     head_ += std::to_string(ep_.port);
   }
@@ -185,9 +193,53 @@ Error HttpConn::Begin(const HttpRequestSpec* spec, HttpResponseData* resp, Reque
   return Error::Success();
 }
 
+bool HttpConn::Reconnect() {
+  retried_ = true;
+  Close();
+  Error e = OpenSocket();
+  if (!e.IsOk()) {
+    Fail(e);
+    return false;
+  }
+  reused_ = false;
+  piece_ = piece_off_ = 0;
+  state_ = State::CONNECTING;
+  return true;
+}
+
 bool HttpConn::SendSome() {
-  // gather up to 16 pieces per writev: {head_, body pieces...}
   const size_t total_pieces = 1 + spec_->body.size();
+  if (tls_) {
+    // TLS records are built by the session: one piece at a time, no gather
+    tls_blocked_ = false;
+    while (piece_ < total_pieces) {
+      const uint8_t* base = piece_ == 0 ? reinterpret_cast<const uint8_t*>(head_.data()) : spec_->body[piece_ - 1].first;
+      const size_t len = piece_ == 0 ? head_.size() : spec_->body[piece_ - 1].second;
+      if (piece_off_ >= len) {
+        ++piece_;
+        piece_off_ = 0;
+        continue;
+      }
+      const ssize_t n = tls_->Write(base + piece_off_, len - piece_off_);
+      if (n == net::TlsSession::kWouldBlock) {
+        tls_blocked_ = true;
+        return false;
+      }
+      if (n < 0) {
+        if (reused_ && !retried_) {
+          Reconnect();
+          return false;
+        }
+        Fail(Error(tls_->LastError(), 503));
+        return false;
+      }
+      piece_off_ += static_cast<size_t>(n);
+    }
+    if (timers_) timers_->CaptureTimestamp(RequestTimers::Kind::SEND_END);
+    state_ = State::READ_HEAD;
+    return true;
+  }
+  // gather up to 16 pieces per writev: {head_, body pieces...}
   while (piece_ < total_pieces) {
     struct iovec iov[16];
     int n = 0;
@@ -217,13 +269,7 @@ bool HttpConn::SendSome() {
       if (errno == EINTR) continue;
       // stale keep-alive connection: reconnect once and resend from scratch
       if (reused_ && !retried_ && (errno == EPIPE || errno == ECONNRESET)) {
-        retried_ = true;
-        Close();
-        Error e = OpenSocket();
-        if (!e.IsOk()) { Fail(e); return false; }
-        reused_ = false;
-        piece_ = piece_off_ = 0;
-        state_ = State::CONNECTING;
+        Reconnect();
         return false;
       }
       Fail(Error(std::string("send failed: ") + std::strerror(errno), 503));
@@ -253,6 +299,20 @@ bool HttpConn::SendSome() {
   return true;
 }
 
+ssize_t HttpConn::RecvRaw(void* buf, size_t len) {
+  if (!tls_) return ::recv(fd_, buf, len, 0);
+  tls_blocked_ = false;
+  const ssize_t n = tls_->Read(buf, len);
+  if (n >= 0) return n;
+  if (n == net::TlsSession::kWouldBlock) {
+    tls_blocked_ = true;
+    errno = EAGAIN;
+  } else {
+    errno = EPROTO;
+  }
+  return -1;
+}
+
 bool HttpConn::RecvSome() {
   char buf[65536];
   // large bodies: read straight into the destination once its size is known
@@ -260,7 +320,7 @@ bool HttpConn::RecvSome() {
     const size_t have = resp_->body.size();
     const size_t want = body_expected_ - have;
     resp_->body.resize(body_expected_);
-    ssize_t n = ::recv(fd_, &resp_->body[have], want, 0);
+    ssize_t n = RecvRaw(&resp_->body[have], want);
     if (n > 0) {
       resp_->body.resize(have + static_cast<size_t>(n));
       return true;
@@ -268,10 +328,10 @@ bool HttpConn::RecvSome() {
     resp_->body.resize(have);
     if (n == 0) { Fail(Error("connection closed by peer mid-body", 503)); return false; }
     if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) return false;
-    Fail(Error(std::string("recv failed: ") + std::strerror(errno), 503));
+    Fail(Error(tls_ && errno == EPROTO ? tls_->LastError() : std::string("recv failed: ") + std::strerror(errno), 503));
     return false;
   }
-  ssize_t n = ::recv(fd_, buf, sizeof(buf), 0);
+  ssize_t n = RecvRaw(buf, sizeof(buf));
   if (n > 0) {
     if (!recv_started_) {
       recv_started_ = true;
@@ -290,13 +350,7 @@ bool HttpConn::RecvSome() {
     }
     if (state_ == State::READ_HEAD && reused_ && !retried_ && rbuf_.empty()) {
       // server dropped the idle connection before reading our request
-      retried_ = true;
-      Close();
-      Error e = OpenSocket();
-      if (!e.IsOk()) { Fail(e); return false; }
-      reused_ = false;
-      piece_ = piece_off_ = 0;
-      state_ = State::CONNECTING;
+      Reconnect();
       return false;
     }
     Fail(Error("connection closed by peer", 503));
@@ -304,16 +358,10 @@ bool HttpConn::RecvSome() {
   }
   if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) return false;
   if (state_ == State::READ_HEAD && reused_ && !retried_ && rbuf_.empty() && errno == ECONNRESET) {
-    retried_ = true;
-    Close();
-    Error e = OpenSocket();
-    if (!e.IsOk()) { Fail(e); return false; }
-    reused_ = false;
-    piece_ = piece_off_ = 0;
-    state_ = State::CONNECTING;
+    Reconnect();
     return false;
   }
-  Fail(Error(std::string("recv failed: ") + std::strerror(errno), 503));
+  Fail(Error(tls_ && errno == EPROTO ? tls_->LastError() : std::string("recv failed: ") + std::strerror(errno), 503));
   return false;
 }
 
@@ -420,6 +468,26 @@ void HttpConn::Pump() {
         getsockopt(fd_, SOL_SOCKET, SO_ERROR, &err, &len);
         if (err != 0) {
           Fail(Error("unable to connect to " + ep_.host + ":" + std::to_string(ep_.port) + ": " + std::strerror(err), 503));
+          return;
+        }
+        if (ep_.https) {
+          if (!ep_.tls) {
+            Fail(Error("https endpoint without a TLS context", 400));
+            return;
+          }
+          tls_.reset(new net::TlsSession(ep_.tls, ep_.host, fd_));
+          state_ = State::TLS_HANDSHAKE;
+          break;
+        }
+        state_ = State::SENDING;
+        if (timers_) timers_->CaptureTimestamp(RequestTimers::Kind::SEND_START);
+        break;
+      }
+      case State::TLS_HANDSHAKE: {
+        const int rc = tls_->Handshake();
+        if (rc == net::TlsSession::kWouldBlock) return;
+        if (rc != 1) {
+          Fail(Error(tls_->LastError(), 503));
           return;
         }
         state_ = State::SENDING;

@@ -21,6 +21,7 @@
 #include "tca/common.h"
 #include "tca/error.h"
 #include "tca/h2.h"
+#include "tca/tls.h"
 
 namespace tca {
 namespace client {
@@ -50,8 +51,10 @@ class GrpcChannel {
     std::function<void(int status, const std::string& message)> on_done;
   };
 
+  // `tls` non-null: the connection is TLS with ALPN "h2" (the context must offer it).
   static Error Create(std::shared_ptr<GrpcChannel>* channel, const std::string& url, bool verbose,
-                      const KeepAliveOptions& keepalive = KeepAliveOptions());
+                      const KeepAliveOptions& keepalive = KeepAliveOptions(),
+                      std::shared_ptr<net::TlsContext> tls = nullptr);
   ~GrpcChannel();
 
   // Starts a call on "/inference.GRPCInferenceService/<method>".  Never fails
@@ -69,7 +72,8 @@ class GrpcChannel {
   const std::string& Url() const { return url_; }
 
  private:
-  GrpcChannel(std::string url, std::string host, int port, bool verbose, const KeepAliveOptions& keepalive);
+  GrpcChannel(std::string url, std::string host, int port, bool verbose, const KeepAliveOptions& keepalive,
+              std::shared_ptr<net::TlsContext> tls);
   struct Call {
     uint32_t stream = 0;
     CallEvents events;
@@ -103,6 +107,8 @@ class GrpcChannel {
   const KeepAliveOptions keepalive_;
 
   int fd_ = -1;
+  std::shared_ptr<net::TlsContext> tls_context_;
+  std::unique_ptr<net::TlsSession> tls_;
   int epfd_ = -1;
   int wake_fd_ = -1;
   std::unique_ptr<h2::Connection> conn_;

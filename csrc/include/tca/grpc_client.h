@@ -12,8 +12,8 @@
 // tca/pbwire.h) because the toolchain has neither grpc++ nor protobuf; control
 // RPC answers are returned as JSON text with the .proto field names (the shape
 // the HTTP client returns) instead of generated message objects; request
-// compression (gzip / deflate) is done with zlib; TLS is not compiled in (an
-// SSL request fails at Create).
+// compression (gzip / deflate) is done with zlib; TLS runs on the in-tree
+// session layer (tca/tls.h, OpenSSL) with ALPN "h2".
 #pragma once
 
 #include <memory>
@@ -26,6 +26,8 @@
 namespace tca {
 namespace client {
 
+// PEM file paths (reference `grpc_client.h:43-60`); an empty root_certificates uses
+// the system trust store.
 struct SslOptions {
   std::string root_certificates, private_key, certificate_chain;
 };

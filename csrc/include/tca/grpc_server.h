@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "tca/error.h"
+#include "tca/tls.h"
 
 namespace tca {
 namespace server {
@@ -43,6 +44,10 @@ class GrpcServerFront {
                   Handlers handlers);
   ~GrpcServerFront();
 
+  // Serve TLS (ALPN "h2") instead of cleartext HTTP/2; call before Start().
+  // `context` must be a server context (TlsOptions::server).
+  void SetTls(std::shared_ptr<net::TlsContext> context) { tls_ = std::move(context); }
+
   Error Start();
   void Stop();
   int port() const { return port_; }
@@ -63,6 +68,7 @@ class GrpcServerFront {
   int nthreads_;
   std::set<std::string> streaming_;
   Handlers handlers_;
+  std::shared_ptr<net::TlsContext> tls_;
   std::vector<std::unique_ptr<Reactor>> reactors_;
   std::atomic<bool> running_{false};
   std::atomic<uint64_t> accepted_{0};

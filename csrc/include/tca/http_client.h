@@ -22,12 +22,19 @@
 namespace tca {
 namespace client {
 
+// TLS settings, used when the server url starts with "https://" (reference
+// `src/c++/library/http_client.h:45-78`; there the values go to libcurl, here to
+// the in-tree TLS session, `tca/tls.h`).
 struct HttpSslOptions {
-  // TLS is not compiled into this build; the struct exists so callers written
-  // against the reference signature keep compiling.
-  bool verify_peer = true;
-  bool verify_host = true;
-  std::string ca_info, cert, key;
+  enum CERTTYPE { CERT_PEM = 0, CERT_DER = 1 };
+  enum KEYTYPE { KEY_PEM = 0, KEY_DER = 1 };
+  long verify_peer = 1;  // 0 = accept any certificate
+  long verify_host = 2;  // 0 = do not compare the certificate's names with the host (curl's 0 / 2 convention)
+  std::string ca_info;   // PEM bundle of trusted CAs; empty = system default
+  CERTTYPE cert_type = CERT_PEM;
+  std::string cert;      // client certificate file
+  KEYTYPE key_type = KEY_PEM;
+  std::string key;       // client private key file
 };
 
 class InferResultHttp;

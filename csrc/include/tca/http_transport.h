@@ -24,6 +24,7 @@
 
 #include "tca/common.h"
 #include "tca/error.h"
+#include "tca/tls.h"
 
 namespace tca {
 namespace client {
@@ -62,14 +63,16 @@ struct HttpEndpoint {
   std::string host;
   int port = 80;
   std::string base_path;  // "" or "/prefix"
+  bool https = false;     // the url carried the https:// scheme
+  std::shared_ptr<net::TlsContext> tls;  // set for https endpoints before the first connection
 };
 
-// Splits "host:port[/base]" (no scheme).
+// Splits "[http://|https://]host[:port][/base]"; the port defaults to 80 / 443.
 Error ParseHttpUrl(const std::string& url, HttpEndpoint* out);
 
 class HttpConn {
  public:
-  enum class State { IDLE, CONNECTING, SENDING, READ_HEAD, READ_BODY, READ_CHUNKED, READ_TO_CLOSE, DONE, FAILED };
+  enum class State { IDLE, CONNECTING, TLS_HANDSHAKE, SENDING, READ_HEAD, READ_BODY, READ_CHUNKED, READ_TO_CLOSE, DONE, FAILED };
 
   explicit HttpConn(const HttpEndpoint& ep) : ep_(ep) {}
   ~HttpConn() { Close(); }
@@ -90,7 +93,12 @@ class HttpConn {
   int fd() const { return fd_; }
   // bumps every time a new socket is opened (fd numbers get reused by the kernel)
   uint64_t generation() const { return generation_; }
-  bool WantsWrite() const { return state_ == State::CONNECTING || state_ == State::SENDING; }
+  // direction to wait for; a TLS session may need the opposite of what the HTTP state suggests
+  bool WantsWrite() const {
+    if (state_ == State::TLS_HANDSHAKE) return tls_ && tls_->WantsWrite();
+    if (tls_ && tls_blocked_) return tls_->WantsWrite();
+    return state_ == State::CONNECTING || state_ == State::SENDING;
+  }
   bool Reusable() const { return fd_ >= 0 && keep_alive_ && state_ == State::DONE; }
   uint64_t deadline_ns() const { return deadline_ns_; }
   void Fail(const Error& e);
@@ -101,12 +109,16 @@ class HttpConn {
   void BuildHead();
   bool SendSome();
   bool RecvSome();   // false when nothing more can be done right now
+  ssize_t RecvRaw(void* buf, size_t len);  // recv() semantics (errno) over the socket or the TLS session
+  bool Reconnect();  // stale keep-alive connection: open a fresh socket and start over
   bool ParseHead();
   bool ParseChunks();
   void Finish();
 
   HttpEndpoint ep_;
   int fd_ = -1;
+  std::unique_ptr<net::TlsSession> tls_;
+  bool tls_blocked_ = false;  // the last TLS call returned kWouldBlock
   uint64_t generation_ = 0;
   State state_ = State::IDLE;
   Error error_;

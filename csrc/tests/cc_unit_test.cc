@@ -109,7 +109,15 @@ TEST(UrlParsing) {
   EXPECT_EQ(ep.base_path, std::string("/base/path"));
   ASSERT_OK(tc::ParseHttpUrl("[::1]:9000", &ep));
   EXPECT_EQ(ep.host, std::string("::1"));
-  EXPECT_TRUE(!tc::ParseHttpUrl("http://localhost:8000", &ep).IsOk());
+  ASSERT_OK(tc::ParseHttpUrl("http://localhost:8000", &ep));
+  EXPECT_TRUE(!ep.https);
+  EXPECT_EQ(ep.port, 8000);
+  ASSERT_OK(tc::ParseHttpUrl("https://example.org/v2prefix", &ep));
+  EXPECT_TRUE(ep.https);
+  EXPECT_EQ(ep.port, 443);
+  EXPECT_EQ(ep.host, std::string("example.org"));
+  EXPECT_EQ(ep.base_path, std::string("/v2prefix"));
+  EXPECT_TRUE(!tc::ParseHttpUrl("https://:8000", &ep).IsOk());
 }
 
 namespace {

@@ -792,8 +792,17 @@ SERVER_TEST(GrpcChannelCacheAndConnectFailure) {
   const tca::Error e = dead->IsServerLive(&live);
   EXPECT_TRUE(!e.IsOk());
   EXPECT_EQ(e.Code(), int(tc::kGrpcUnavailable));
+  // a TLS client against the cleartext port: the handshake fails, the call reports UNAVAILABLE
   std::unique_ptr<tc::InferenceServerGrpcClient> ssl;
-  EXPECT_ERROR_CONTAINS(tc::InferenceServerGrpcClient::Create(&ssl, g_url, false, true), "TLS");
+  ASSERT_OK(tc::InferenceServerGrpcClient::Create(&ssl, g_url, false, true));
+  const tca::Error tls_err = ssl->IsServerLive(&live);
+  EXPECT_TRUE(!tls_err.IsOk());
+  EXPECT_EQ(tls_err.Code(), int(tc::kGrpcUnavailable));
+  // unreadable credentials are reported at Create
+  tc::SslOptions bad_ssl;
+  bad_ssl.root_certificates = "/nonexistent/ca.pem";
+  std::unique_ptr<tc::InferenceServerGrpcClient> bad;
+  EXPECT_ERROR_CONTAINS(tc::InferenceServerGrpcClient::Create(&bad, g_url, false, true, bad_ssl), "CA certificates");
 }
 
 int main(int argc, char** argv) {

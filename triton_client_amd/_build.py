@@ -72,11 +72,12 @@ def build_pyext(force=False):
     suffix = sysconfig.get_config_var("EXT_SUFFIX")
     out = LIBDIR / f"_tca_pyext{suffix}"
     srcs = [CSRC / "capi" / "pyext.cc", CSRC / "capi" / "py_grpc_front.cc", CSRC / "grpc" / "grpc_server.cc",
-            CSRC / "grpc" / "grpc_compress.cc", CSRC / "h2" / "hpack.cc", CSRC / "h2" / "connection.cc"]
+            CSRC / "grpc" / "grpc_compress.cc", CSRC / "h2" / "hpack.cc", CSRC / "h2" / "connection.cc",
+            CSRC / "net" / "tls.cc"]
     if force or _stale(out, srcs):
         LIBDIR.mkdir(exist_ok=True)
         inc = sysconfig.get_paths()["include"]
-        _compile_atomic(["g++", *CXXFLAGS, "-I", inc, "-shared", "-o", out, *srcs, "-pthread", "-lz"], out)
+        _compile_atomic(["g++", *CXXFLAGS, "-I", inc, "-shared", "-o", out, *srcs, "-pthread", "-lssl", "-lcrypto", "-lz"], out)
     return out
 
 

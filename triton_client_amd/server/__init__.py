@@ -28,7 +28,8 @@ class Server:
     """In-process server.  ``http_port`` / ``grpc_port`` of 0 pick free ports."""
 
     def __init__(self, models=None, gpu=None, http_port=0, grpc_port=0, host="127.0.0.1", model_control="none",
-                 enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32, grpc_impl=None):
+                 enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32, grpc_impl=None,
+                 tls_cert=None, tls_key=None, tls_client_ca=None):
         self.core = InferenceCore(models=models, gpu=gpu, model_control=model_control)
         self.host = host
         self._http_port = http_port
@@ -40,6 +41,9 @@ class Server:
         # "native": C++ HTTP/2 reactors + asynchronous completion; "grpcio": the stock
         # Python gRPC server.  Default from TCA_GRPC_IMPL, else native.
         self._grpc_impl = (grpc_impl or os.environ.get("TCA_GRPC_IMPL") or "native").lower()
+        # TLS on both fronts when a certificate + key (PEM files) are given; `tls_client_ca`
+        # additionally requires client certificates signed by that CA (mutual TLS)
+        self._tls = (tls_cert, tls_key, tls_client_ca) if tls_cert and tls_key else None
         self._loop = None
         self._thread = None
         self.http = None
@@ -58,11 +62,12 @@ class Server:
             if self._grpc_impl == "native":
                 from .native_grpc_front import NativeGrpcFront
 
-                self.grpc = NativeGrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers)
+                self.grpc = NativeGrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers,
+                                            tls=self._tls)
             elif self._grpc_impl == "grpcio":
                 from .grpc_front import GrpcFront
 
-                self.grpc = GrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers)
+                self.grpc = GrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers, tls=self._tls)
             else:
                 raise ValueError(f"unknown gRPC implementation '{self._grpc_impl}' (native | grpcio)")
             self._grpc_port = self.grpc.start()
@@ -76,7 +81,8 @@ class Server:
                 loop = asyncio.new_event_loop()
                 asyncio.set_event_loop(loop)
                 self._loop = loop
-                self.http = HttpFront(self.core, self.host, self._http_port, workers=self._http_workers)
+                self.http = HttpFront(self.core, self.host, self._http_port, workers=self._http_workers,
+                                      tls=self._tls)
                 try:
                     self._http_port = loop.run_until_complete(self.http.start())
                 except Exception as e:  # bind failure

@@ -360,10 +360,11 @@ class Servicer(service_pb2_grpc.GRPCInferenceServiceServicer):
 
 
 class GrpcFront:
-    def __init__(self, core, host="127.0.0.1", port=8001, workers=32):
+    def __init__(self, core, host="127.0.0.1", port=8001, workers=32, tls=None):
         self.core = core
         self.host = host
         self.port = port
+        self._tls = tls  # (certificate chain, private key, client CA or None) as PEM file paths
         self.server = grpc.server(
             futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="tca-grpc-srv"),
             options=[("grpc.max_send_message_length", 2**31 - 1), ("grpc.max_receive_message_length", 2**31 - 1),
@@ -372,7 +373,18 @@ class GrpcFront:
         service_pb2_grpc.add_GRPCInferenceServiceServicer_to_server(Servicer(core), self.server)
 
     def start(self):
-        self.port = self.server.add_insecure_port(f"{self.host}:{self.port}")
+        if self._tls:
+            cert, key, client_ca = self._tls
+            with open(key, "rb") as kf, open(cert, "rb") as cf:
+                pair = (kf.read(), cf.read())
+            roots = None
+            if client_ca:
+                with open(client_ca, "rb") as rf:
+                    roots = rf.read()
+            creds = grpc.ssl_server_credentials([pair], root_certificates=roots, require_client_auth=bool(client_ca))
+            self.port = self.server.add_secure_port(f"{self.host}:{self.port}", creds)
+        else:
+            self.port = self.server.add_insecure_port(f"{self.host}:{self.port}")
         if self.port == 0:
             raise RuntimeError("could not bind the gRPC port")
         self.server.start()

@@ -241,17 +241,28 @@ class _HttpProtocol(asyncio.Protocol):
 
 
 class HttpFront:
-    def __init__(self, core, host="127.0.0.1", port=8000, workers=16):
+    def __init__(self, core, host="127.0.0.1", port=8000, workers=16, tls=None):
         self.core = core
         self.host = host
         self.port = port
+        self._tls = tls  # (certificate chain, private key, client CA or None) as PEM file paths
         self.pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="tca-http-srv")
         self.server = None
 
     async def start(self):
         loop = asyncio.get_running_loop()
+        context = None
+        if self._tls:
+            import ssl
+
+            cert, key, client_ca = self._tls
+            context = ssl.SSLContext(ssl.PROTOCOL_TLS_SERVER)
+            context.load_cert_chain(cert, key)
+            if client_ca:
+                context.load_verify_locations(client_ca)
+                context.verify_mode = ssl.CERT_REQUIRED
         self.server = await loop.create_server(lambda: _HttpProtocol(self), self.host, self.port, reuse_address=True,
-                                               backlog=1024)
+                                               backlog=1024, ssl=context)
         self.port = self.server.sockets[0].getsockname()[1]
         return self.port
 

@@ -57,7 +57,7 @@ class _Stream:
 
 
 class NativeGrpcFront:
-    def __init__(self, core, host="127.0.0.1", port=8001, workers=16, reactors=2):
+    def __init__(self, core, host="127.0.0.1", port=8001, workers=16, reactors=2, tls=None):
         from .._native import pyext
 
         self.core = core
@@ -85,8 +85,11 @@ class NativeGrpcFront:
                 with lock:
                     self._prof.runcall(_inner, call, method, data)
 
+        kwargs = {}
+        if tls:  # (certificate chain, private key, client CA or None) as PEM file paths
+            kwargs = {"tls_cert": tls[0], "tls_key": tls[1], "tls_client_ca": tls[2]}
         self._front = pyext().GrpcFront(host, int(port), int(reactors), on_unary, self._on_stream_message,
-                                        self._on_stream_end, self._on_cancel)
+                                        self._on_stream_end, self._on_cancel, **kwargs)
 
     def start(self):
         self.port = self._front.start()
