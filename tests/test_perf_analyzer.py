@@ -67,3 +67,31 @@ def test_multi_endpoint_sharding_and_string_model(two_servers):
         with g.InferenceServerClient(srv.grpc_url) as c:
             st = c.get_inference_statistics("simple_string", as_json=True)
             assert int(st["model_stats"][0]["inference_stats"]["success"]["count"]) > 0
+
+
+@pytest.mark.parametrize("proto,shm", [("grpc", "none"), ("http", "system"), ("grpc", "system")])
+def test_native_generator_mode(two_servers, proto, shm):
+    """--native: levels are driven by tca_loadgen processes, one per endpoint."""
+    from triton_client_amd import _build
+
+    _build.build_cpp()
+    a, b = two_servers
+    urls = f"{a.grpc_url},{b.grpc_url}" if proto == "grpc" else f"{a.http_url},{b.http_url}"
+    rows = _run(["-m", "simple", "--urls", urls, "-i", proto, "-b", "2", "--shared-memory", shm, "--native",
+                 "--concurrency-range", "2:4:2", "-p", "200", "--stability-windows", "2", "--warmup-ms", "100"])
+    assert [r["level"] for r in rows] == [2, 4]
+    for r in rows:
+        assert r["errors"] == 0 and r["stable"] and r["requests"] > 20
+        assert r["infer_per_sec"] == pytest.approx(r["requests_per_sec"] * 2, rel=1e-3)
+        assert 0 < r["p50_us"] <= r["p99_us"]
+    # regions were unregistered again
+    import tritonclient.grpc as g
+
+    with g.InferenceServerClient(a.grpc_url) as c:
+        assert not c.get_system_shared_memory_status(as_json=True).get("regions")
+
+
+def test_native_mode_rejects_open_loop(two_servers):
+    a, _ = two_servers
+    with pytest.raises(SystemExit):
+        _run(["-m", "simple", "-u", a.grpc_url, "--native", "--request-rate-range", "100"])
