@@ -122,11 +122,12 @@ inline void ValidateSimple(tc::InferResult* result, const std::vector<int32_t>& 
   size_t n = 0;
   FAIL_IF_ERR(result->RawData("OUTPUT0", &buf, &n), "unable to get OUTPUT0");
   if (n != a.size() * 4) FAIL("unexpected OUTPUT0 size " << n);
-  const int32_t* o0 = reinterpret_cast<const int32_t*>(buf);
+  const uint8_t* o0 = buf;
   FAIL_IF_ERR(result->RawData("OUTPUT1", &buf, &n), "unable to get OUTPUT1");
-  const int32_t* o1 = reinterpret_cast<const int32_t*>(buf);
+  if (n != a.size() * 4) FAIL("unexpected OUTPUT1 size " << n);
+  const uint8_t* o1 = buf;
   for (size_t i = 0; i < a.size(); ++i) {
-    if (o0[i] != a[i] + b[i]) FAIL("incorrect sum at " << i);
-    if (o1[i] != a[i] - b[i]) FAIL("incorrect difference at " << i);
+    if (tca::LoadAs<int32_t>(o0, i) != a[i] + b[i]) FAIL("incorrect sum at " << i);
+    if (tca::LoadAs<int32_t>(o1, i) != a[i] - b[i]) FAIL("incorrect difference at " << i);
   }
 }

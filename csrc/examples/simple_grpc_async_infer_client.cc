@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "example_utils.h"
+#include "tca/sync.h"
 
 int main(int argc, char** argv) {
   CommonFlags flags = ParseCommonFlags(argc, argv);
@@ -35,7 +36,7 @@ int main(int argc, char** argv) {
   }
   {
     std::unique_lock<std::mutex> lk(mu);
-    if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return results.size() == kRequests; }))
+    if (!tca::WaitFor(cv, lk, std::chrono::seconds(30), [&] { return results.size() == kRequests; }))
       FAIL("timed out waiting for the responses");
   }
   for (auto& r : results) {

@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "example_utils.h"
+#include "tca/sync.h"
 
 int main(int argc, char** argv) {
   CommonFlags flags = ParseCommonFlags(argc, argv);
@@ -32,7 +33,7 @@ int main(int argc, char** argv) {
                     const uint8_t* buf = nullptr;
                     size_t n = 0;
                     if (!is_null && r->RawData("OUT", &buf, &n).IsOk() && n == 4)
-                      outs.push_back(*reinterpret_cast<const int32_t*>(buf));
+                      outs.push_back(tca::LoadAs<int32_t>(buf));
                     if (is_final || !status.IsOk()) final_seen = true;
                     cv.notify_all();
                   },
@@ -53,7 +54,7 @@ int main(int argc, char** argv) {
   FAIL_IF_ERR(client->AsyncStreamInfer(options, {in.get(), delay.get(), w.get()}), "stream request");
   {
     std::unique_lock<std::mutex> lk(mu);
-    if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return final_seen; })) FAIL("timed out");
+    if (!tca::WaitFor(cv, lk, std::chrono::seconds(60), [&] { return final_seen; })) FAIL("timed out");
   }
   FAIL_IF_ERR(client->StopStream(), "unable to stop the stream");
   if (!failure.empty()) FAIL(failure);

@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "example_utils.h"
+#include "tca/sync.h"
 
 int main(int argc, char** argv) {
   CommonFlags flags = ParseCommonFlags(argc, argv);
@@ -34,7 +35,7 @@ int main(int argc, char** argv) {
                       const uint8_t* buf = nullptr;
                       size_t n = 0;
                       if (r->RawData("OUTPUT", &buf, &n).IsOk() && n == 4)
-                        got[id.substr(0, id.find('_'))].push_back(*reinterpret_cast<const int32_t*>(buf));
+                        got[id.substr(0, id.find('_'))].push_back(tca::LoadAs<int32_t>(buf));
                     }
                     cv.notify_all();
                   },
@@ -57,7 +58,7 @@ int main(int argc, char** argv) {
   }
   {
     std::unique_lock<std::mutex> lk(mu);
-    if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return received == total; })) FAIL("timed out");
+    if (!tca::WaitFor(cv, lk, std::chrono::seconds(30), [&] { return received == total; })) FAIL("timed out");
   }
   FAIL_IF_ERR(client->StopStream(), "unable to stop the stream");
   if (!failure.empty()) FAIL(failure);

@@ -16,7 +16,7 @@ static int32_t Send(tc::InferenceServerGrpcClient* client, const std::string& mo
   const uint8_t* buf = nullptr;
   size_t n = 0;
   FAIL_IF_ERR(result->RawData("OUTPUT", &buf, &n), "OUTPUT");
-  const int32_t out = *reinterpret_cast<const int32_t*>(buf);
+  const int32_t out = tca::LoadAs<int32_t>(buf);
   delete result;
   return out;
 }

@@ -1,5 +1,6 @@
 // Native gRPC client (see tca/grpc_client.h).
 #include "tca/grpc_client.h"
+#include "tca/sync.h"
 
 #include <condition_variable>
 #include <cstdlib>
@@ -962,11 +963,11 @@ Error InferenceServerGrpcClient::StopStream() {
   stream_.reset();
   channel_->CloseSend(st->call);
   std::unique_lock<std::mutex> lk(st->mu);
-  if (!st->cv.wait_for(lk, std::chrono::seconds(30), [&] { return st->done; })) {
+  if (!tca::WaitFor(st->cv, lk, std::chrono::seconds(30), [&] { return st->done; })) {
     lk.unlock();
     channel_->Cancel(st->call);
     lk.lock();
-    st->cv.wait_for(lk, std::chrono::seconds(5), [&] { return st->done; });
+    tca::WaitFor(st->cv, lk, std::chrono::seconds(5), [&] { return st->done; });
   }
   return Error::Success();
 }

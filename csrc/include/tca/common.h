@@ -10,6 +10,8 @@
 // InferInput, so one InferInput can be part of several in-flight requests.
 #pragma once
 
+#include <cstring>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -27,6 +29,17 @@
 #include "tca/error.h"
 
 namespace tca {
+
+// Element `index` of a tensor buffer as returned by InferResult::RawData.  Tensor
+// bytes sit at arbitrary offsets inside a response body (after a JSON header, after
+// a BYTES tensor), so they must not be read through a typed pointer.
+template <typename T>
+inline T LoadAs(const uint8_t* buf, size_t index = 0) {
+  T value;
+  std::memcpy(&value, buf + index * sizeof(T), sizeof(T));
+  return value;
+}
+
 namespace client {
 
 constexpr char kInferHeaderContentLengthHTTPHeader[] = "Inference-Header-Content-Length";

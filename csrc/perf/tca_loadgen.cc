@@ -27,6 +27,7 @@
 #include <thread>
 
 #include "tca/codec.h"
+#include "tca/sync.h"
 #include "tca/grpc_client.h"
 #include "tca/http_client.h"
 
@@ -239,7 +240,7 @@ int main(int argc, char** argv) {
     }
     for (int s = 0; s < first_wave; ++s) issue(s);
     std::unique_lock<std::mutex> lk(mu);
-    cv.wait_for(lk, std::chrono::seconds(900), [&] { return to_finish <= 0 && outstanding == 0; });
+    tca::WaitFor(cv, lk, std::chrono::seconds(900), [&] { return to_finish <= 0 && outstanding == 0; });
     return (last_done_ns - t_start) / 1e9;
   };
   // Time-based: warm up, then record for `seconds`.
@@ -268,7 +269,7 @@ int main(int argc, char** argv) {
       stopping = true;
     }
     std::unique_lock<std::mutex> lk(mu);
-    cv.wait_for(lk, std::chrono::seconds(60), [&] { return outstanding == 0; });
+    tca::WaitFor(cv, lk, std::chrono::seconds(60), [&] { return outstanding == 0; });
     return (t1 - t0) / 1e9;
   };
 

@@ -54,12 +54,12 @@ void CheckResult(tc::InferResult* res, const Request& req, bool want0, bool want
   if ((want0 && !swapped) || (want1 && swapped)) {
     EXPECT_OK(res->RawData(add_name, &buf, &n));
     EXPECT_EQ(n, size_t(64));
-    for (int i = 0; n == 64 && i < 16; ++i) EXPECT_EQ(reinterpret_cast<const int32_t*>(buf)[i], req.in0[i] + req.in1[i]);
+    for (int i = 0; n == 64 && i < 16; ++i) EXPECT_EQ(tca::LoadAs<int32_t>(buf, i), req.in0[i] + req.in1[i]);
   }
   if ((want1 && !swapped) || (want0 && swapped)) {
     EXPECT_OK(res->RawData(sub_name, &buf, &n));
     EXPECT_EQ(n, size_t(64));
-    for (int i = 0; n == 64 && i < 16; ++i) EXPECT_EQ(reinterpret_cast<const int32_t*>(buf)[i], req.in0[i] - req.in1[i]);
+    for (int i = 0; n == 64 && i < 16; ++i) EXPECT_EQ(tca::LoadAs<int32_t>(buf, i), req.in0[i] - req.in1[i]);
   }
   if (!want0) EXPECT_TRUE(!res->RawData("OUTPUT0", &buf, &n).IsOk());
   if (!want1) EXPECT_TRUE(!res->RawData("OUTPUT1", &buf, &n).IsOk());

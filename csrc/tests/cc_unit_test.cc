@@ -205,11 +205,11 @@ TEST(JsonOutputToBinaryEveryDatatype) {
   ASSERT_OK(res->RawData("i16", &buf, &n));
   EXPECT_TRUE(n == 4 && reinterpret_cast<const int16_t*>(buf)[0] == -2 && reinterpret_cast<const int16_t*>(buf)[1] == 300);
   ASSERT_OK(res->RawData("i32", &buf, &n));
-  EXPECT_TRUE(n == 16 && reinterpret_cast<const int32_t*>(buf)[3] == -4);
+  EXPECT_TRUE(n == 16 && tca::LoadAs<int32_t>(buf, 3) == -4);
   ASSERT_OK(res->RawData("u64", &buf, &n));
   EXPECT_TRUE(n == 8 && *reinterpret_cast<const uint64_t*>(buf) == 18446744073709551615ull);
   ASSERT_OK(res->RawData("f32", &buf, &n));
-  EXPECT_TRUE(n == 8 && reinterpret_cast<const float*>(buf)[0] == 1.5f && reinterpret_cast<const float*>(buf)[1] == 2.f);
+  EXPECT_TRUE(n == 8 && tca::LoadAs<float>(buf, 0) == 1.5f && tca::LoadAs<float>(buf, 1) == 2.f);
   ASSERT_OK(res->RawData("f64", &buf, &n));
   EXPECT_TRUE(n == 16 && reinterpret_cast<const double*>(buf)[0] == 0.1);  // 8-byte doubles, not floats
   std::vector<std::string> strs;
@@ -239,9 +239,15 @@ TEST(MixedBinaryResponse) {
   const uint8_t* buf = nullptr;
   size_t n = 0;
   ASSERT_OK(res->RawData("A", &buf, &n));
-  EXPECT_TRUE(n == 8 && reinterpret_cast<const int32_t*>(buf)[1] == -6);
+  // tensors sit at arbitrary offsets inside the response body: no aligned loads
+  auto load_i32 = [](const uint8_t* p) {
+    int32_t v;
+    std::memcpy(&v, p, sizeof(v));
+    return v;
+  };
+  EXPECT_TRUE(n == 8 && load_i32(buf + 4) == -6);
   ASSERT_OK(res->RawData("J", &buf, &n));
-  EXPECT_TRUE(n == 4 && *reinterpret_cast<const int32_t*>(buf) == 9);
+  EXPECT_TRUE(n == 4 && load_i32(buf) == 9);
   std::vector<std::string> strs;
   ASSERT_OK(res->StringData("B", &strs));
   EXPECT_TRUE(strs.size() == 1 && strs[0] == "hi");

@@ -19,6 +19,7 @@
 
 #include "minitest.h"
 #include "tca/grpc_client.h"
+#include "tca/sync.h"
 #include "tca/h2.h"
 #include "tca/json.h"
 #include "tca/pbjson.h"
@@ -290,7 +291,7 @@ TEST(InferRequestEncodingAndResponseParsing) {
   size_t n = 0;
   EXPECT_OK(result->RawData("A", &buf, &n));
   EXPECT_EQ(n, size_t(8));
-  if (n == 8) EXPECT_EQ(reinterpret_cast<const int32_t*>(buf)[1], 6);
+  if (n == 8) EXPECT_EQ(tca::LoadAs<int32_t>(buf, 1), 6);
   std::vector<std::string> strings;
   EXPECT_OK(result->StringData("B", &strings));
   EXPECT_EQ(strings.size(), size_t(2));
@@ -335,10 +336,10 @@ void CheckSums(tc::InferResult* res, const Request& req, bool swapped = false) {
   size_t n = 0;
   EXPECT_OK(res->RawData(swapped ? "OUTPUT1" : "OUTPUT0", &buf, &n));
   EXPECT_EQ(n, size_t(64));
-  for (int i = 0; n == 64 && i < 16; ++i) EXPECT_EQ(reinterpret_cast<const int32_t*>(buf)[i], req.in0[i] + req.in1[i]);
+  for (int i = 0; n == 64 && i < 16; ++i) EXPECT_EQ(tca::LoadAs<int32_t>(buf, i), req.in0[i] + req.in1[i]);
   EXPECT_OK(res->RawData(swapped ? "OUTPUT0" : "OUTPUT1", &buf, &n));
   EXPECT_EQ(n, size_t(64));
-  for (int i = 0; n == 64 && i < 16; ++i) EXPECT_EQ(reinterpret_cast<const int32_t*>(buf)[i], req.in0[i] - req.in1[i]);
+  for (int i = 0; n == 64 && i < 16; ++i) EXPECT_EQ(tca::LoadAs<int32_t>(buf, i), req.in0[i] - req.in1[i]);
 }
 
 std::unique_ptr<tc::InferenceServerGrpcClient> NewClient(bool cached = true) {
@@ -521,7 +522,7 @@ SERVER_TEST(GrpcAsyncInferManyInFlight) {
   }
   {
     std::unique_lock<std::mutex> lk(mu);
-    EXPECT_TRUE(cv.wait_for(lk, std::chrono::seconds(30), [&] { return done == kN; }));
+    EXPECT_TRUE(tca::WaitFor(cv, lk, std::chrono::seconds(30), [&] { return done == kN; }));
   }
   for (int i = 0; i < kN; ++i) {
     ASSERT_OK(results[i] ? tca::Error::Success() : tca::Error("missing result"));
@@ -567,7 +568,7 @@ SERVER_TEST(GrpcInferMultiVariants) {
       },
       one, inputs));
   std::unique_lock<std::mutex> lk(mu);
-  EXPECT_TRUE(cv.wait_for(lk, std::chrono::seconds(30), [&] { return done; }));
+  EXPECT_TRUE(tca::WaitFor(cv, lk, std::chrono::seconds(30), [&] { return done; }));
   EXPECT_EQ(async_results.size(), size_t(4));
   for (size_t i = 0; i < async_results.size(); ++i) {
     CheckSums(async_results[i], *reqs[i]);
@@ -658,7 +659,7 @@ SERVER_TEST(GrpcStreamSequencesInterleaved) {
       r->Id(&id);
       const uint8_t* buf;
       size_t n;
-      if (r->RawData("OUTPUT", &buf, &n).IsOk() && n == 4) got[id.substr(0, id.find('_'))].push_back(*reinterpret_cast<const int32_t*>(buf));
+      if (r->RawData("OUTPUT", &buf, &n).IsOk() && n == 4) got[id.substr(0, id.find('_'))].push_back(tca::LoadAs<int32_t>(buf));
     }
     cv.notify_all();
   }));
@@ -681,7 +682,7 @@ SERVER_TEST(GrpcStreamSequencesInterleaved) {
   }
   {
     std::unique_lock<std::mutex> lk(mu);
-    EXPECT_TRUE(cv.wait_for(lk, std::chrono::seconds(30), [&] { return received == 16; }));
+    EXPECT_TRUE(tca::WaitFor(cv, lk, std::chrono::seconds(30), [&] { return received == 16; }));
   }
   EXPECT_OK(c->StopStream());
   EXPECT_EQ(got["1001"].size(), size_t(8));
@@ -715,7 +716,7 @@ SERVER_TEST(GrpcDecoupledRepeat) {
         r->IsFinalResponse(&is_final);
         const uint8_t* buf;
         size_t n;
-        if (!is_null && r->RawData("OUT", &buf, &n).IsOk() && n == 4) outs.push_back(*reinterpret_cast<const int32_t*>(buf));
+        if (!is_null && r->RawData("OUT", &buf, &n).IsOk() && n == 4) outs.push_back(tca::LoadAs<int32_t>(buf));
         if (is_final) ++finals;
         cv.notify_all();
       },
@@ -736,7 +737,7 @@ SERVER_TEST(GrpcDecoupledRepeat) {
   ASSERT_OK(c->AsyncStreamInfer(opt, {in, delay, w}));
   {
     std::unique_lock<std::mutex> lk(mu);
-    EXPECT_TRUE(cv.wait_for(lk, std::chrono::seconds(30), [&] { return finals == 1; }));
+    EXPECT_TRUE(tca::WaitFor(cv, lk, std::chrono::seconds(30), [&] { return finals == 1; }));
   }
   EXPECT_OK(c->StopStream());
   EXPECT_EQ(outs.size(), size_t(5));
