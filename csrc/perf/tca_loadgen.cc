@@ -10,6 +10,8 @@
 //       --wait-go            (with --count) print READY after the warm-up and start the
 //                            measured phase when a line arrives on stdin
 //       --connections M      gRPC: spread the slots over M channels (default 1)
+//       --trace FILE         write one CSV row per measured request:
+//                            start_ns (since the measured phase began), latency_ns, slot, ok
 //       --shape NAME:DATATYPE:d0,d1,...      wire tensors (zero filled)
 //       --shm-input NAME:DATATYPE:dims:REGION:BYTES[:OFFSET]   registered shm input
 //       --shm-output NAME:REGION:BYTES[:OFFSET]
@@ -72,6 +74,7 @@ int main(int argc, char** argv) {
   bool wait_go = false;
   double duration = 5.0, warmup = 1.0;
   std::vector<std::string> shapes, shm_in, shm_out;
+  std::string trace_path;
   for (int i = 1; i < argc; ++i) {
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
     if (!std::strcmp(argv[i], "-u")) url = next();
@@ -82,6 +85,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--warmup-count")) warmup_count = std::atoll(next());
     else if (!std::strcmp(argv[i], "--wait-go")) wait_go = true;
     else if (!std::strcmp(argv[i], "--connections")) connections = std::max(1, std::atoi(next()));
+    else if (!std::strcmp(argv[i], "--trace")) trace_path = next();
     else if (!std::strcmp(argv[i], "-c")) concurrency = std::atoi(next());
     else if (!std::strcmp(argv[i], "-b")) batch = std::atoi(next());
     else if (!std::strcmp(argv[i], "-d")) duration = std::atof(next());
@@ -173,6 +177,13 @@ int main(int argc, char** argv) {
   bool record = false;      // completions of this phase go into `latencies`
   bool open_ended = false;  // duration phase: re-issue until `stopping`
   bool stopping = false;
+  struct TraceRow {
+    uint64_t start_ns, latency_ns;
+    int slot;
+    bool ok;
+  };
+  const bool tracing = !trace_path.empty();
+  std::vector<TraceRow> trace_rows;
   long long to_issue = 0;   // count phase: requests still to be issued
   long long to_finish = 0;  // count phase: completions still owed
   int outstanding = 0;
@@ -196,6 +207,7 @@ int main(int argc, char** argv) {
         } else if (record) {
           latencies.push_back(t1 - slots[s]->t0);
         }
+        if (record && tracing) trace_rows.push_back({slots[s]->t0, t1 - slots[s]->t0, s, status.IsOk()});
         if (open_ended) {
           again = !stopping;
         } else {
@@ -292,6 +304,21 @@ int main(int argc, char** argv) {
   {
     std::lock_guard<std::mutex> lk(mu);
     lat = latencies;
+  }
+  if (tracing) {
+    std::FILE* fh = std::fopen(trace_path.c_str(), "w");
+    if (fh == nullptr) {
+      std::cerr << "cannot write " << trace_path << std::endl;
+      return 1;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    uint64_t origin = ~0ull;
+    for (const auto& r : trace_rows) origin = std::min(origin, r.start_ns);
+    std::fprintf(fh, "start_ns,latency_ns,slot,ok\n");
+    for (const auto& r : trace_rows)
+      std::fprintf(fh, "%llu,%llu,%d,%d\n", static_cast<unsigned long long>(r.start_ns - origin),
+                   static_cast<unsigned long long>(r.latency_ns), r.slot, r.ok ? 1 : 0);
+    std::fclose(fh);
   }
   std::sort(lat.begin(), lat.end());
   auto pct = [&](double p) -> double {

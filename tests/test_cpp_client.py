@@ -90,14 +90,21 @@ def test_cpp_grpc_example_variants(built, server, name, extra):
     assert "PASS" in _run([os.path.join(built, name), "-u", server.grpc_url, *extra])
 
 
-def test_native_loadgen_grpc_fixed_count(built, server):
+def test_native_loadgen_grpc_fixed_count(built, server, tmp_path):
+    import csv
     import json
 
+    trace = tmp_path / "trace.csv"
     out = _run([os.path.join(built, "tca_loadgen"), "-u", server.grpc_url, "-i", "grpc", "-m", "simple", "-c", "8",
                 "--count", "500", "--warmup-count", "50", "--connections", "2", "--shape", "INPUT0:INT32:1,16",
-                "--shape", "INPUT1:INT32:1,16"])
+                "--shape", "INPUT1:INT32:1,16", "--trace", str(trace)])
     stats = json.loads(out.strip().splitlines()[-1])
     assert stats["errors"] == 0 and stats["requests"] == 500 and stats["protocol"] == "grpc"
+    # --trace: one row per measured request (the warm-up is not traced)
+    with open(trace) as fh:
+        rows = list(csv.DictReader(fh))
+    assert len(rows) == 500 and min(int(r["start_ns"]) for r in rows) == 0
+    assert all(r["ok"] == "1" and int(r["latency_ns"]) > 0 and 0 <= int(r["slot"]) < 8 for r in rows)
 
 
 @pytest.mark.parametrize("name", CPP_EXAMPLES)

@@ -95,3 +95,48 @@ def test_native_mode_rejects_open_loop(two_servers):
     a, _ = two_servers
     with pytest.raises(SystemExit):
         _run(["-m", "simple", "-u", a.grpc_url, "--native", "--request-rate-range", "100"])
+
+
+def test_resume_skips_finished_levels(two_servers, tmp_path):
+    a, _ = two_servers
+    progress = tmp_path / "progress.json"
+    base = ["-m", "simple", "-u", a.grpc_url, "-p", "200", "--warmup-ms", "50", "-r", "3", "-s", "60",
+            "--stability-windows", "2", "--worker-processes", "1", "--resume", str(progress)]
+    first = _run(base + ["--concurrency-range", "1:2"])
+    assert [r["level"] for r in first] == [1, 2]
+    # same settings, longer range: levels 1 and 2 come from the file (bit-identical rows), 3 is measured
+    second = _run(base + ["--concurrency-range", "1:3"])
+    assert [r["level"] for r in second] == [1, 2, 3]
+    assert second[0] == first[0] and second[1] == first[1]
+    import json
+
+    assert [r["level"] for r in json.load(open(progress))["rows"]] == [1, 2, 3]
+    # different settings invalidate the file
+    third = _run(base + ["--concurrency-range", "1", "-b", "2"])
+    assert third[0]["level"] == 1 and third[0] != first[0]
+
+
+def test_gpu_metrics_sampling(two_servers, tmp_path, monkeypatch):
+    """--gpu-metrics with a stand-in rocm-smi on PATH (no GPU in CI)."""
+    import json
+    import os
+    import stat
+
+    from triton_client_amd.perf.analyzer import GpuSampler
+
+    sample = {"card0": {"GPU use (%)": "80", "Average Graphics Package Power (W)": "500.0",
+                        "GPU Memory Allocated (VRAM%)": "10"},
+              "card1": {"GPU use (%)": "60", "Current Socket Graphics Package Power (W)": "300.0",
+                        "GPU Memory Allocated (VRAM%)": "30"},
+              "system": {"Driver version": "6.0"}}
+    parsed = GpuSampler.parse(json.dumps(sample))
+    assert parsed == {"gpu_util_pct": 70.0, "gpu_power_w": 400.0, "gpu_mem_pct": 20.0}
+
+    tool = tmp_path / "rocm-smi"
+    tool.write_text("#!/bin/sh\ncat <<'JSON'\n" + json.dumps(sample) + "\nJSON\n")
+    tool.chmod(tool.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", f"{tmp_path}{os.pathsep}{os.environ['PATH']}")
+    a, _ = two_servers
+    rows = _run(["-m", "simple", "-u", a.grpc_url, "--concurrency-range", "2", "-p", "400", "--warmup-ms", "50", "-r",
+                 "3", "-s", "60", "--stability-windows", "2", "--worker-processes", "1", "--gpu-metrics"])
+    assert rows[0]["gpu_util_pct"] == 70.0 and rows[0]["gpu_power_w"] == 400.0 and rows[0]["gpu_mem_pct"] == 20.0

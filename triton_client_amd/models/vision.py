@@ -24,6 +24,8 @@ import os
 import threading
 from collections import OrderedDict
 
+from ..utils import trace as _trace
+
 from .base import Model, ModelError, TensorSpec, register
 
 def install_miopen_db():
@@ -318,7 +320,7 @@ class ResNet50(Model):
             if graph is None:
                 graph = self._capture(x, out)
                 self._graphs.put(key, graph)
-            with torch.cuda.stream(self._stream):
+            with torch.cuda.stream(self._stream), _trace.range(f"resnet50 graph replay b={batch}"):
                 graph[0].replay()
         return out
 

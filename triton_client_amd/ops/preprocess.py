@@ -29,6 +29,7 @@ import ctypes
 
 import numpy as np
 
+from ..utils import trace as _trace
 from . import _bind
 from ._device import DeviceBuffer, PinnedBuffer, Stream, as_pointer, check, lib, stream_handle
 
@@ -135,6 +136,10 @@ class Preprocessor:
 
     # -- run --
     def __call__(self, images, out, out_offset=0, bgr=False, stream=None, synchronize=True):
+        with _trace.range(f"hip preprocess n={len(images)}"):
+            return self._run(images, out, out_offset, bgr, stream, synchronize)
+
+    def _run(self, images, out, out_offset=0, bgr=False, stream=None, synchronize=True):
         """Preprocess ``images`` into ``out``.
 
         images : list of HWC / HW uint8 numpy arrays (host), or of CUDA uint8

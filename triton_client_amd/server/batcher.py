@@ -21,6 +21,7 @@ import time
 import numpy as np
 
 from ..models import ModelError
+from ..utils import trace as _trace
 from .core import ServerError
 
 
@@ -210,6 +211,10 @@ class DynamicBatcher:
         return bufs
 
     def _launch(self, group, total):
+        with _trace.range(f"batch {self.model.name} n={len(group)} b={total}"):
+            return self._launch_inner(group, total)
+
+    def _launch_inner(self, group, total):
         import torch
 
         model, core, lm = self.model, self.core, self.lm

@@ -14,7 +14,7 @@ protocol.
   handle),
 * per-model statistics, trace and log settings,
 * sequence state, the dynamic batcher for GPU models and fault injection knobs
-  (``delay_ms`` / ``fail_every_n`` model parameters).
+  (``delay_ms`` / ``fail_every_n`` / ``drop_stream_after_n`` model parameters).
 
 The HTTP and gRPC fronts translate their wire format to :class:`InferRequest`
 and back from :class:`InferResponse`.
@@ -40,6 +40,7 @@ from ..utils import (
     triton_to_np_dtype,
 )
 from ..utils import shared_memory as sysshm
+from ..utils import trace as _trace
 
 SERVER_NAME = "triton"
 SERVER_VERSION = "2.50.0-mi355x"
@@ -266,7 +267,8 @@ class DeviceShmRegistry:
             if name in self._regions:
                 raise ServerError(f"shared memory region '{name}' already in manager", 400)
             try:
-                mapping = hipshm.open_shared_memory_region(name, raw_handle, byte_size, device_id)
+                with _trace.range(f"hipIpcOpenMemHandle {name}"):
+                    mapping = hipshm.open_shared_memory_region(name, raw_handle, byte_size, device_id)
             except Exception as e:
                 raise ServerError(f"failed to register device shared memory region '{name}': {e}", 400) from None
             self._regions[name] = (int(device_id), int(byte_size), mapping)
@@ -722,6 +724,19 @@ class InferenceCore:
             lm.request_counter += 1
             if lm.request_counter % int(every) == 0:
                 raise ServerError(f"injected failure for model '{lm.model.name}' (fail_every_n={every})", 500)
+
+    def stream_drop_after(self, name):
+        """Fault injection for streaming clients: ``drop_stream_after_n`` (model
+        parameter) makes a gRPC front abort a stream with UNAVAILABLE once it has
+        written that many responses of this model on it.  0 = never."""
+        with self._lock:
+            lm = self._loaded.get(name)
+        if lm is None:
+            return 0
+        try:
+            return int(lm.model.parameters.get("drop_stream_after_n") or 0)
+        except (TypeError, ValueError):
+            return 0
 
     def uses_batcher(self, name):
         """Whether requests for ``name`` complete asynchronously (GPU model

@@ -352,11 +352,19 @@ class Servicer(service_pb2_grpc.GRPCInferenceServiceServicer):
                     out.put(_EOS)
 
         threading.Thread(target=reader, name="tca-grpc-stream-reader", daemon=True).start()
+        written = {}  # model name -> responses written on this stream (fault injection only)
         while True:
             item = out.get()
             if item is _EOS:
                 return
             yield item
+            name = item.infer_response.model_name
+            limit = self.core.stream_drop_after(name) if name else 0
+            if limit:
+                written[name] = written.get(name, 0) + 1
+                if written[name] >= limit:
+                    context.abort(grpc.StatusCode.UNAVAILABLE,
+                                  f"injected stream failure for model '{name}' (drop_stream_after_n={limit})")
 
 
 class GrpcFront:

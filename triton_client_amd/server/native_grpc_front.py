@@ -45,7 +45,7 @@ class _Context:
 
 
 class _Stream:
-    __slots__ = ("lock", "pending", "ended", "ordered", "draining", "closed")
+    __slots__ = ("lock", "pending", "ended", "ordered", "draining", "closed", "written")
 
     def __init__(self):
         self.lock = threading.Lock()
@@ -54,6 +54,7 @@ class _Stream:
         self.ordered = collections.deque()  # sequence requests: executed one at a time, in arrival order
         self.draining = False
         self.closed = False
+        self.written = {}       # model name -> responses written (fault injection only)
 
 
 class NativeGrpcFront:
@@ -216,6 +217,24 @@ class NativeGrpcFront:
         self._front.send(call, err.SerializeToString())
         self._stream_done(call, st)
 
+    def _stream_send(self, call, st, model_name, message):
+        """Write one stream response; applies the ``drop_stream_after_n`` fault knob."""
+        self._front.send(call, message.SerializeToString())
+        limit = self.core.stream_drop_after(model_name)
+        if not limit:
+            return
+        with st.lock:
+            st.written[model_name] = st.written.get(model_name, 0) + 1
+            drop = st.written[model_name] >= limit and not st.closed
+            if drop:
+                st.closed = True
+                st.ordered.clear()
+        if drop:
+            self._front.finish(call, _UNAVAILABLE,
+                               f"injected stream failure for model '{model_name}' (drop_stream_after_n={limit})")
+            with self._streams_lock:
+                self._streams.pop(call, None)
+
     def _stream_done(self, call, st):
         with st.lock:
             st.pending -= 1
@@ -232,8 +251,8 @@ class NativeGrpcFront:
             if err is not None:
                 self._stream_error(call, st, msg, str(getattr(err, "message", err)))
                 return
-            self._front.send(call, pb.ModelStreamInferResponse(
-                infer_response=response_to_proto(resp)).SerializeToString())
+            self._stream_send(call, st, req.model_name, pb.ModelStreamInferResponse(
+                infer_response=response_to_proto(resp)))
             self._stream_done(call, st)
 
         try:
@@ -244,8 +263,10 @@ class NativeGrpcFront:
                 done(result, None)
                 return
             for item in result:  # decoupled model: any number of responses
-                self._front.send(call, pb.ModelStreamInferResponse(
-                    infer_response=response_to_proto(item)).SerializeToString())
+                if st.closed:
+                    break
+                self._stream_send(call, st, req.model_name, pb.ModelStreamInferResponse(
+                    infer_response=response_to_proto(item)))
             self._stream_done(call, st)
         except ServerError as e:
             self._stream_error(call, st, msg, e.message)
