@@ -129,7 +129,7 @@ def test_gpu_metrics_sampling(two_servers, tmp_path, monkeypatch):
               "card1": {"GPU use (%)": "60", "Current Socket Graphics Package Power (W)": "300.0",
                         "GPU Memory Allocated (VRAM%)": "30"},
               "system": {"Driver version": "6.0"}}
-    parsed = GpuSampler.parse(json.dumps(sample))
+    parsed = GpuSampler.parse("WARNING: AMD GPU device(s) is/are in a low-power state.\n\n" + json.dumps(sample))
     assert parsed == {"gpu_util_pct": 70.0, "gpu_power_w": 400.0, "gpu_mem_pct": 20.0}
 
     tool = tmp_path / "rocm-smi"

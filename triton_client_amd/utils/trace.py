@@ -7,7 +7,7 @@ preprocessing, IPC handle opening).  The reference has no client-side tracing
 this is the MI355X-side addition.
 
 Off by default: every call is a cheap no-op until ``enable()`` is called or the
-process starts with ``TCA_ROCTX=1``.  A missing ``libroctx64.so`` also leaves
+process starts with ``TCA_ROCTX=1``.  A missing ROCTx library also leaves
 everything a no-op.
 """
 
@@ -31,7 +31,10 @@ def _load():
     with _lock:
         if _lib is not None or _load_failed:
             return _lib
-        for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+        # rocprofv3 (rocprofiler-sdk) records markers from its own ROCTx library; the older
+        # libroctx64 (roctracer) has the same entry points and serves older profilers
+        for name in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                     "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
             try:
                 lib = ctypes.CDLL(name)
                 lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
