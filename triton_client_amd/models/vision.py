@@ -180,6 +180,10 @@ class ResNet50(Model):
         self.use_graphs = True
         # hand-written fused kernels (default) vs the plain library forward
         self.fused = os.environ.get("TCA_RESNET_FUSED", "1") != "0"
+        # projection shortcuts on a parallel graph branch.  Off: measured on MI355X the
+        # cross-queue dependencies of a forked HIP graph cost more than the overlap wins
+        # (b8 0.590 vs 0.526 ms, b128 2.626 vs 2.614 ms); kept as an A/B switch.
+        self.overlap_shortcut = os.environ.get("TCA_RESNET_OVERLAP", "0") != "0"
 
     # -- lifecycle --
     def load(self, device_index=None):
@@ -214,6 +218,7 @@ class ResNet50(Model):
         self._net = net
         self._build_plan()
         self._stream = torch.cuda.Stream(device=self._device)
+        self._side_stream = torch.cuda.Stream(device=self._device)
         # immediate mode + the shipped tuned databases; TCA_MIOPEN_TUNE=1 runs
         # MIOpen's exhaustive search instead (tools/tune_miopen.py)
         torch.backends.cudnn.benchmark = os.environ.get("TCA_MIOPEN_TUNE", "0") == "1"
@@ -288,10 +293,24 @@ class ResNet50(Model):
         # Cin = 3: library kernel; its bias + ReLU ride in the pooling pass
         w4, bias, stride, pad = stem
         y = conv.bias_relu_maxpool(F.conv2d(x, w4, None, stride=stride, padding=pad), bias)
+        main = torch.cuda.current_stream()
+        side = self._side_stream if self.overlap_shortcut else None
         for a, mid, c, down in blocks:
-            identity = y if down is None else pointwise(y, down, None, False)
+            if down is None:
+                identity = y
+            elif side is None:
+                identity = pointwise(y, down, None, False)
+            else:
+                # the projection shortcut only depends on the block input: run it on a second
+                # stream (a parallel branch of the captured graph) next to the block's first two
+                # convolutions, so it fills the tails those leave on the 256 CUs
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    identity = pointwise(y, down, None, False)
             t = pointwise(y, a, None, True)
             t = spatial(t, mid)
+            if down is not None and side is not None:
+                main.wait_stream(side)
             y = pointwise(t, c, identity, True)
         return y.mean(dim=(2, 3))
 
