@@ -41,7 +41,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--concurrency", type=int, default=int(os.environ.get("TCA_BENCH_CONCURRENCY", "64")))
-    ap.add_argument("--requests-per-step", type=int, default=64)
+    ap.add_argument("--requests-per-step", type=int, default=256,
+                    help="requests per GPU that make up one timed step")
     ap.add_argument("--protocol", choices=["grpc", "http"], default="grpc")
     ap.add_argument("--shared-memory", choices=["hip", "system", "none"], default="hip")
     ap.add_argument("--model", default="resnet50")
