@@ -22,8 +22,9 @@
 //                   passes.
 //   BiasReluMaxPoolKernel  the stem's epilogue folded into its 3x3/2 max pooling.
 //
-// GEMM structure: 256 threads = 4 wavefronts (2x2), block tile BM x BN, K step
-// 64, v_mfma_f32_16x16x32_f16.  The weight tile is the MFMA A operand and the
+// GEMM structure: 4 wavefronts (2x2) or 8 (2x4), block tile BM x BN, K step
+// 64, v_mfma_f32_16x16x32_f16.  The 8-wavefront 128x128 tile (64x32 per wave)
+// keeps twice the waves per SIMD in flight for the same LDS footprint.  The weight tile is the MFMA A operand and the
 // activation tile the B operand, i.e. the wave computes Y^T fragments: each
 // lane then owns 4 CONSECUTIVE output channels of one pixel, which packs into
 // one 8-byte LDS store for the epilogue transpose.  Tiles are staged by
@@ -95,17 +96,20 @@ __device__ __forceinline__ void DmaToLds(__amdgpu_buffer_rsrc_t rsrc, unsigned v
                                            static_cast<int>(voffset), soffset, 0, 0);
 }
 
-template <int BM, int BN, bool kSpatial, bool kGlds>
-__global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds>
+__global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias,
                                                           const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ Y, int M, int N, int K, int relu,
                                                           RowMap map, int tiles_n, int xcd_chunk, unsigned x_bytes,
                                                           int stages) {
-  constexpr int kAVecs = BM * 8 / kThreads;  // 16-byte vectors per thread and stage (activation tile)
-  constexpr int kWVecs = BN * 8 / kThreads;  // (weight tile)
+  constexpr int kW = 2 * kWN;                // wavefronts: 2 along m x kWN along n
+  constexpr int kT = 64 * kW;                // threads
+  constexpr int kAVecs = BM * 8 / kT;        // 16-byte vectors per thread and stage (activation tile)
+  constexpr int kWVecs = BN * 8 / kT;        // (weight tile)
   constexpr int kMI = BM / 32;               // 16-wide fragments per wave along m
-  constexpr int kNI = BN / 32;               // along n
+  constexpr int kNI = BN / (16 * kWN);       // along n
+  static_assert(kAVecs >= 1 && kWVecs >= 1 && kNI >= 1, "tile too small for the wave layout");
   constexpr int kStageHalfs = (BM + BN) * kBK;
   constexpr int kCPitch = BN + 8;  // halfs; 16-byte aligned rows, spreads the transposed stores over banks
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
   const int lane = tid & 63;
   // the wave index as a scalar: LDS-DMA destinations and fragment bases stay in SGPR arithmetic
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1;  // wave row (m)
-  const int wn = wave & 1;   // wave column (n)
+  const int wm = wave / kWN;  // wave row (m)
+  const int wn = wave % kWN;  // wave column (n)
 
   // ---- direct-to-LDS staging state -------------------------------------------------
   // The LDS image of one wave instruction is linear (lane l lands at base + 16*l), so
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
   if constexpr (kGlds) {
 #pragma unroll
     for (int i = 0; i < kAVecs; ++i) {
-      const int v = (i * 4 + wave) * 64 + lane;
+      const int v = (i * kW + wave) * 64 + lane;
       const int row = v >> 3;
       const int chunk = (v & 7) ^ ((row >> 1) & 7);
       const int m = m0 + row;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
     }
 #pragma unroll
     for (int i = 0; i < kWVecs; ++i) {
-      const int v = (i * 4 + wave) * 64 + lane;
+      const int v = (i * kW + wave) * 64 + lane;
       const int row = v >> 3;
       const int chunk = (v & 7) ^ ((row >> 1) & 7);
       w_off[i] = static_cast<unsigned>(((n0 + row) * K + chunk * 8) * 2);  // N % BN == 0 (host checked)
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
       const unsigned bit = 1u << next_tap;
 #pragma unroll
       for (int i = 0; i < kAVecs; ++i)
-        DmaToLds(x_rsrc, (a_taps[i] & bit) ? a_off[i] : kOutOfRange, soff, base + (i * 4 + wave) * 512);
+        DmaToLds(x_rsrc, (a_taps[i] & bit) ? a_off[i] : kOutOfRange, soff, base + (i * kW + wave) * 512);
       next_c0 += kBK;
       if (next_c0 == map.cin) {
         next_c0 = 0;
@@ -199,10 +203,10 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < kAVecs; ++i) DmaToLds(x_rsrc, a_off[i], next_k0 * 2, base + (i * 4 + wave) * 512);
+      for (int i = 0; i < kAVecs; ++i) DmaToLds(x_rsrc, a_off[i], next_k0 * 2, base + (i * kW + wave) * 512);
     }
 #pragma unroll
-    for (int i = 0; i < kWVecs; ++i) DmaToLds(w_rsrc, w_off[i], next_k0 * 2, base + BM * kBK + (i * 4 + wave) * 512);
+    for (int i = 0; i < kWVecs; ++i) DmaToLds(w_rsrc, w_off[i], next_k0 * 2, base + BM * kBK + (i * kW + wave) * 512);
     next_k0 += kBK;
   };
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
   if constexpr (!kGlds) {
 #pragma unroll
     for (int i = 0; i < kAVecs; ++i) {
-      const int v = tid + i * kThreads;
+      const int v = tid + i * kT;
       const int row = v >> 3;
       const int chunk = v & 7;
       const int m = m0 + row;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
     }
 #pragma unroll
     for (int i = 0; i < kWVecs; ++i) {
-      const int v = tid + i * kThreads;
+      const int v = tid + i * kT;
       const int row = v >> 3;
       const int chunk = v & 7;
       w_src[i] = W + static_cast<long long>(n0 + row) * K + chunk * 8;  // N % BN == 0 (host checked)
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
   const int frag_row = lane & 15;
   const int frag_chunk = (lane >> 4) ^ ((frag_row >> 1) & 7);
   const int xf_off = (wm * (BM / 2) + frag_row) * kBK + frag_chunk * 8;
-  const int wf_off = BM * kBK + (wn * (BN / 2) + frag_row) * kBK + frag_chunk * 8;
+  const int wf_off = BM * kBK + (wn * (BN / kWN) + frag_row) * kBK + frag_chunk * 8;
   auto compute_tile = [&](int stage) {
     const _Float16* base = lds + stage * kStageHalfs;
 #pragma unroll
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
   _Float16* cs = lds;
 #pragma unroll
   for (int ni = 0; ni < kNI; ++ni) {
-    const int n_local = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+    const int n_local = wn * (BN / kWN) + ni * 16 + (lane >> 4) * 4;
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr) {
       const half4 bv = *reinterpret_cast<const half4*>(bias + n0 + n_local);
@@ -374,10 +378,10 @@ __global__ __launch_bounds__(kThreads) void ConvGemmKernel(const _Float16* __res
 
   // coalesced 16-byte epilogue: residual add, ReLU, store
   constexpr int kRowVecs = BN / 8;
-  constexpr int kOutVecs = BM * kRowVecs / kThreads;
+  constexpr int kOutVecs = BM * kRowVecs / kT;
 #pragma unroll
   for (int i = 0; i < kOutVecs; ++i) {
-    const int v = tid + i * kThreads;
+    const int v = tid + i * kT;
     const int row = v / kRowVecs;
     const int cv = v - row * kRowVecs;
     const int m = m0 + row;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void BiasReluMaxPoolKernel(const _Float16
   }
 }
 
-template <int BM, int BN, bool kSpatial, bool kGlds>
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM;
@@ -484,11 +488,11 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
   if (lds_bytes > 64 * 1024) {
     // above the default dynamic-LDS limit: raise it once per kernel instantiation
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kSpatial, kGlds>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
   }
-  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kSpatial, kGlds>), dim3(blocks), dim3(kThreads), lds_bytes, st, x, w, bias, residual, y, M,
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds>), dim3(blocks), dim3(128 * kWN), lds_bytes, st, x, w, bias, residual, y, M,
                      N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
@@ -500,7 +504,8 @@ extern "C" {
 
 // x: [batch,in_h,in_w,cin] fp16, w: [cout][ksize][ksize][cin] fp16 (the memory of
 // a channels-last [cout,cin,ksize,ksize] weight), y: [batch,oh,ow,cout].
-// variant: low 4 bits 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile;
+// variant: low 4 bits 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile (4 wavefronts),
+// 4 = 128x128, 5 = 256x128 (8 wavefronts);
 // bit 4 selects register staging; bits 5-6 the number of LDS stages (2 or 3).
 int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                          int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu, int variant,
@@ -536,20 +541,20 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
   if (x_bytes_ll + lead_bytes >= 0x7FFFFFFFll || k_ll * cout * 2 >= 0x7FFFFFFFll || ksize * ksize > 32) staging = 1;
   const unsigned x_bytes = staging ? 0u : static_cast<unsigned>(x_bytes_ll);
   if (variant == 0) {
-    // thresholds from per-layer timings (tools/conv_bench.py): a long K loop with
-    // enough 128x128 tiles to cover the chip is compute-bound and wants the most
-    // reuse per staged byte; otherwise enough blocks to fill 256 CUs several times
-    // over first, then the bigger tile
+    // thresholds from per-layer timings (tools/conv_bench.py, batches 8..128): the
+    // 128x128 tile on 8 wavefronts wins as soon as it yields about one block per CU
+    // and the K loop is long enough to amortise its prologue; below that, enough
+    // 64x64 blocks to fill 256 CUs several times over first, then 128x64
     const long long blocks128 = static_cast<long long>((M + 127) / 128) * (cout / 128);
     const long long blocks64 = static_cast<long long>((M + 63) / 64) * (cout / 64);
-    if (cout % 128 == 0 && K >= 512 && blocks128 >= 256) variant = 1;
+    if (cout % 128 == 0 && ((K >= 128 && blocks128 >= 196) || blocks128 >= 4096)) variant = 4;
     else variant = blocks64 <= 2048 ? 3 : 2;
   }
-  if (variant == 1 && cout % 128 != 0) return -2;
+  if ((variant == 1 || variant == 4 || variant == 5) && cout % 128 != 0) return -2;
   if (stages != 2 && stages != 3) {
     // a third stage hides more DMA latency but costs LDS: take it only when the grid is
     // too small for the LDS limit on resident blocks to bind
-    const int bm = variant == 3 ? 64 : 128, bn = variant == 1 ? 128 : 64;
+    const int bm = variant == 3 ? 64 : (variant == 5 ? 256 : 128), bn = (variant == 2 || variant == 3) ? 64 : 128;
     const long long blocks = static_cast<long long>((M + bm - 1) / bm) * (cout / bn);
     const long long per_cu_wanted = (blocks + 255) / 256;
     const long long per_cu_with_3 = (160 * 1024) / (3 * (bm + bn) * kBK * 2);
@@ -562,15 +567,17 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
   auto rp = static_cast<const _Float16*>(residual);
   auto yp = static_cast<_Float16*>(y);
   // staging: direct-to-LDS DMA by default; `staging` = 1 keeps the register-staged path (A/B testing)
-#define TCA_DISPATCH(BM_, BN_)                                                                                      \
-  (spatial ? (staging ? LaunchConvGemm<BM_, BN_, true, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)       \
-                      : LaunchConvGemm<BM_, BN_, true, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st))       \
-           : (staging ? LaunchConvGemm<BM_, BN_, false, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)      \
-                      : LaunchConvGemm<BM_, BN_, false, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)))
+#define TCA_DISPATCH(BM_, BN_, WN_)                                                                                      \
+  (spatial ? (staging ? LaunchConvGemm<BM_, BN_, WN_, true, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)  \
+                      : LaunchConvGemm<BM_, BN_, WN_, true, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st))  \
+           : (staging ? LaunchConvGemm<BM_, BN_, WN_, false, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st) \
+                      : LaunchConvGemm<BM_, BN_, WN_, false, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)))
   switch (variant) {
-    case 1: return TCA_DISPATCH(128, 128);
-    case 2: return TCA_DISPATCH(128, 64);
-    case 3: return TCA_DISPATCH(64, 64);
+    case 1: return TCA_DISPATCH(128, 128, 2);
+    case 2: return TCA_DISPATCH(128, 64, 2);
+    case 3: return TCA_DISPATCH(64, 64, 2);
+    case 4: return TCA_DISPATCH(128, 128, 4);  // 8 wavefronts, 64x32 per wave
+    case 5: return TCA_DISPATCH(256, 128, 4);  // 8 wavefronts, 128x32 per wave
     default: return -3;
   }
 #undef TCA_DISPATCH

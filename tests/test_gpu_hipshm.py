@@ -131,7 +131,7 @@ def test_simple_over_hipshm_ipc(hipshm, gpu_server, proto):
 
 
 def test_simple_string_over_grpc_hipshm(hipshm, gpu_server):
-    """BASELINE config 2: BYTES tensors over gRPC with device shared-memory I/O."""
+    """BYTES tensors (`simple_string`) over gRPC with device shared-memory I/O."""
     import tritonclient.grpc as mod
     import tritonclient.utils as utils
 
@@ -164,7 +164,7 @@ def test_simple_string_over_grpc_hipshm(hipshm, gpu_server):
 
 
 def test_resnet50_zero_copy_vs_wire(hipshm, gpu_server):
-    """BASELINE config 3: ResNet-50 fp16 batch 8, HIP preprocessing writes into
+    """The flagship configuration: ResNet-50 fp16 batch 8, HIP preprocessing writes into
     the hipshm input region, logits land in the hipshm output region; the wire
     path must give the same answer."""
     import torch

@@ -26,6 +26,9 @@ LAYERS_3X3 = [(56, 56, 64, 1), (56, 56, 128, 2), (28, 28, 128, 1), (28, 28, 256,
               (14, 14, 512, 2), (7, 7, 512, 1)]
 
 
+MFMA_VARIANTS = ("128x128", "128x64", "64x64", "128x128w8", "256x128w8")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="8,32,128")
@@ -59,7 +62,8 @@ def main():
             end.synchronize()
         return start.elapsed_time(end) * 1e3 / (5 * args.reps)  # us per call
 
-    print(f"{'batch':>5} {'layer':>26} {'eager':>8} {'lib+ep':>8} {'128x128':>8} {'128x64':>8} {'64x64':>8}  best", flush=True)
+    print(f"{'batch':>5} {'layer':>26} {'eager':>8} {'lib+ep':>8} " + " ".join(f"{v:>8}" for v in MFMA_VARIANTS) + "  best",
+          flush=True)
     totals = {}
     for b in [int(v) for v in args.batches.split(",")]:
         for (h, w, cin, cout, stride, with_res, relu) in LAYERS:
@@ -87,8 +91,8 @@ def main():
             out = torch.empty(b, cout, oh, ow, device=dev, dtype=torch.float16).contiguous(
                 memory_format=torch.channels_last)
             times = {"eager": graph_time(eager), "lib+ep": graph_time(lib_ep)}
-            for variant in ("128x128", "128x64", "64x64"):
-                if variant == "128x128" and cout % 128:
+            for variant in MFMA_VARIANTS:
+                if "x128" in variant and cout % 128:
                     times[variant] = float("nan")
                     continue
                 times[variant] = graph_time(
@@ -96,12 +100,12 @@ def main():
             best = min((k for k in times if times[k] == times[k]), key=lambda k: times[k])
             name = f"{h}x{w} {cin}->{cout} s{stride}{'+r' if with_res else ''}"
             print(f"{b:5d} {name:>26} " + " ".join(f"{times[k]:8.2f}" for k in
-                                                  ("eager", "lib+ep", "128x128", "128x64", "64x64")) + f"  {best}",
+                                                  ("eager", "lib+ep") + MFMA_VARIANTS) + f"  {best}",
                   flush=True)
             t = totals.setdefault(b, {"eager": 0.0, "lib+ep": 0.0, "mfma_best": 0.0, "best": 0.0})
             t["eager"] += times["eager"]
             t["lib+ep"] += times["lib+ep"]
-            mf = min(times[k] for k in ("128x128", "128x64", "64x64") if times[k] == times[k])
+            mf = min(times[k] for k in MFMA_VARIANTS if times[k] == times[k])
             t["mfma_best"] += mf
             t["best"] += min(mf, times["lib+ep"])
         for (h, w, c, stride) in LAYERS_3X3:
@@ -117,8 +121,8 @@ def main():
                 return conv.bias_act_(F.conv2d(x, wt, None, stride=stride, padding=1), bias, None, True)
 
             times = {"eager": graph_time(eager3), "lib+ep": graph_time(lib_ep3)}
-            for variant in ("128x128", "128x64", "64x64"):
-                if variant == "128x128" and c % 128:
+            for variant in MFMA_VARIANTS:
+                if "x128" in variant and c % 128:
                     times[variant] = float("nan")
                     continue
                 times[variant] = graph_time(
@@ -126,7 +130,7 @@ def main():
             best = min((k for k in times if times[k] == times[k]), key=lambda k: times[k])
             name = f"3x3 {h}x{w} {c}->{c} s{stride}"
             print(f"{b:5d} {name:>26} " + " ".join(f"{times[k]:8.2f}" for k in
-                                                  ("eager", "lib+ep", "128x128", "128x64", "64x64")) + f"  {best}",
+                                                  ("eager", "lib+ep") + MFMA_VARIANTS) + f"  {best}",
                   flush=True)
     for b, t in totals.items():
         print(f"batch {b}: sum over distinct layers (us): " + ", ".join(f"{k}={v:.1f}" for k, v in t.items()), flush=True)

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 from ._device import check, lib
 
-VARIANTS = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3}
+VARIANTS = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3, "128x128w8": 4, "256x128w8": 5}
 # operand staging of the GEMM kernel: "lds" = direct global->LDS DMA (default),
 # "reg" = through registers + ds_write (kept for A/B measurements)
 _REG_STAGING = 16
