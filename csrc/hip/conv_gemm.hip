@@ -548,13 +548,16 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
     const long long blocks128 = static_cast<long long>((M + 127) / 128) * (cout / 128);
     const long long blocks64 = static_cast<long long>((M + 63) / 64) * (cout / 64);
     if (cout % 128 == 0 && ((K >= 128 && blocks128 >= 196) || blocks128 >= 4096)) variant = 4;
-    else variant = blocks64 <= 2048 ? 3 : 2;
+    else if (blocks64 <= 2048) variant = (K >= 512 && blocks64 <= 256) ? 7 : 3;  // few blocks, long K: more waves per block
+    else variant = (cout % 128 != 0 && K >= 256) ? 7 : 2;
   }
   if ((variant == 1 || variant == 4 || variant == 5) && cout % 128 != 0) return -2;
+  if (variant == 8 && cout % 256 != 0) return -2;
   if (stages != 2 && stages != 3) {
     // a third stage hides more DMA latency but costs LDS: take it only when the grid is
     // too small for the LDS limit on resident blocks to bind
-    const int bm = variant == 3 ? 64 : (variant == 5 ? 256 : 128), bn = (variant == 2 || variant == 3) ? 64 : 128;
+    const int bm = (variant == 3 || variant == 7) ? 64 : (variant == 5 ? 256 : 128);
+    const int bn = (variant == 2 || variant == 3 || variant == 6 || variant == 7) ? 64 : (variant == 8 ? 256 : 128);
     const long long blocks = static_cast<long long>((M + bm - 1) / bm) * (cout / bn);
     const long long per_cu_wanted = (blocks + 255) / 256;
     const long long per_cu_with_3 = (160 * 1024) / (3 * (bm + bn) * kBK * 2);
@@ -578,6 +581,9 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
     case 3: return TCA_DISPATCH(64, 64, 2);
     case 4: return TCA_DISPATCH(128, 128, 4);  // 8 wavefronts, 64x32 per wave
     case 5: return TCA_DISPATCH(256, 128, 4);  // 8 wavefronts, 128x32 per wave
+    case 6: return TCA_DISPATCH(128, 64, 4);   // 8 wavefronts, 64x16 per wave
+    case 7: return TCA_DISPATCH(64, 64, 4);    // 8 wavefronts, 32x16 per wave
+    case 8: return TCA_DISPATCH(128, 256, 4);  // 8 wavefronts, 64x64 per wave
     default: return -3;
   }
 #undef TCA_DISPATCH

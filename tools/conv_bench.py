@@ -26,7 +26,7 @@ LAYERS_3X3 = [(56, 56, 64, 1), (56, 56, 128, 2), (28, 28, 128, 1), (28, 28, 256,
               (14, 14, 512, 2), (7, 7, 512, 1)]
 
 
-MFMA_VARIANTS = ("128x128", "128x64", "64x64", "128x128w8", "256x128w8")
+MFMA_VARIANTS = ("128x64", "64x64", "128x128w8", "128x64w8", "64x64w8", "128x256w8")
 
 
 def main():
@@ -92,7 +92,7 @@ def main():
                 memory_format=torch.channels_last)
             times = {"eager": graph_time(eager), "lib+ep": graph_time(lib_ep)}
             for variant in MFMA_VARIANTS:
-                if "x128" in variant and cout % 128:
+                if ("x128" in variant and cout % 128) or ("x256" in variant and cout % 256):
                     times[variant] = float("nan")
                     continue
                 times[variant] = graph_time(
@@ -122,7 +122,7 @@ def main():
 
             times = {"eager": graph_time(eager3), "lib+ep": graph_time(lib_ep3)}
             for variant in MFMA_VARIANTS:
-                if "x128" in variant and c % 128:
+                if ("x128" in variant and c % 128) or ("x256" in variant and c % 256):
                     times[variant] = float("nan")
                     continue
                 times[variant] = graph_time(

@@ -19,7 +19,8 @@ from __future__ import annotations
 
 from ._device import check, lib
 
-VARIANTS = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3, "128x128w8": 4, "256x128w8": 5}
+VARIANTS = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3, "128x128w8": 4, "256x128w8": 5,
+            "128x64w8": 6, "64x64w8": 7, "128x256w8": 8}
 # operand staging of the GEMM kernel: "lds" = direct global->LDS DMA (default),
 # "reg" = through registers + ds_write (kept for A/B measurements)
 _REG_STAGING = 16
@@ -42,12 +43,13 @@ def _variant_code(variant, staging=None):
 def gemm_pays(pixels, cout, k_total):
     """Whether the MFMA GEMM kernel beats library convolution + epilogue pass
     for a layer with ``pixels`` output pixels.  The kernel has no split-K: with
-    few 64x64 output tiles and a long K loop the CUs run one block each and the
-    staging latency of every K step is exposed, which is where the library's
-    split-K kernels win.  Threshold fitted to per-layer timings on MI355X
-    (``tools/conv_bench.py``)."""
+    few 64x64 output tiles and a long K loop every CU runs at most one block and
+    the kernel time is the K loop's latency chain (about a third of a microsecond
+    per 64-wide K step), which is where the library's split-K kernels win.
+    Thresholds fitted to per-layer timings on MI355X (``tools/conv_bench.py``)."""
     tiles = ((pixels + 63) // 64) * (cout // 64)
-    return tiles >= 4.5 * (k_total // 64)
+    ksteps = k_total // 64
+    return ksteps <= 40 or tiles >= 2.5 * ksteps
 
 
 def _stream():
