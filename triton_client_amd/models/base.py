@@ -141,7 +141,7 @@ class Model:
             cfg["sequence_batching"] = {"max_sequence_idle_microseconds": 5000000}
         elif self.dynamic_batching:
             cfg["dynamic_batching"] = {"preferred_batch_size": [self.max_batch_size],
-                                       "max_queue_delay_microseconds": int(getattr(self, "max_queue_delay_us", 100))}
+                                       "max_queue_delay_microseconds": int(getattr(self, "max_queue_delay_us", 0))}
         return copy.deepcopy(cfg)
 
 

@@ -50,7 +50,7 @@ def _profiled(fn, tag):
 
 class _Item:
     __slots__ = ("req", "inputs", "batch", "stable", "requested", "ctx", "stats", "t_arrive", "version", "done",
-                 "response", "error", "t_queued", "callback")
+                 "response", "error", "t_queued", "callback", "gap_ns")
 
     def __init__(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback=None):
         self.req, self.inputs, self.batch, self.stable = req, inputs, batch, stable
@@ -61,6 +61,7 @@ class _Item:
         self.response = None
         self.error = None
         self.t_queued = time.perf_counter_ns()
+        self.gap_ns = 1 << 62  # time since the previous arrival for the same model (set by the batcher)
 
     def finish(self):
         """Hand the outcome to whoever submitted the request."""
@@ -81,7 +82,17 @@ class DynamicBatcher:
         self.lm = lm
         self.model = lm.model
         self.max_batch = max(1, self.model.max_batch_size)
-        self.delay_s = float(getattr(self.model, "max_queue_delay_us", 100)) / 1e6
+        self.delay_s = float(getattr(self.model, "max_queue_delay_us", 0)) / 1e6
+        # Burst coalescing: in a closed loop the answers of one batch go out together, so
+        # the next requests come back as a burst tens of microseconds apart.  When the last
+        # arrival followed its predecessor within `burst_gap_s`, or fewer requests have
+        # come back than the batch answered within the last `burst_gap_s` held, an idle
+        # GPU waits up to `burst_window_s` for the rest of the burst; serial traffic (one
+        # request at a time, gaps of a whole round trip) never waits.
+        self.burst_gap_s = float(getattr(self.model, "burst_gap_us", 300)) / 1e6
+        self.burst_window_s = float(getattr(self.model, "burst_window_us", 100)) / 1e6
+        self._last_arrival_ns = 0
+        self._last_done = (0, 1)  # (time, requests) of the batch that completed last
         self.q = queue.Queue()
         self.completions = queue.Queue()
         self._held = None
@@ -127,6 +138,7 @@ class DynamicBatcher:
     # called on transport threads
     def submit(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version):
         item = _Item(req, inputs, max(1, batch), stable, requested, ctx, stats, t_arrive, version)
+        self._stamp(item)
         self.q.put(item)
         item.done.wait()
         if item.error is not None:
@@ -136,28 +148,56 @@ class DynamicBatcher:
     def submit_async(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback):
         """Queue a request and return at once; ``callback(response, error)`` runs
         on the completer thread (or the batcher thread when the launch fails)."""
-        self.q.put(_Item(req, inputs, max(1, batch), stable, requested, ctx, stats, t_arrive, version, callback))
+        item = _Item(req, inputs, max(1, batch), stable, requested, ctx, stats, t_arrive, version, callback)
+        self._stamp(item)
+        self.q.put(item)
+
+    def _stamp(self, item):
+        # unsynchronised on purpose: a lost update only blurs a heuristic
+        now = item.t_queued
+        item.gap_ns = now - self._last_arrival_ns
+        self._last_arrival_ns = now
 
     # ------------------------------------------------------------ batching
     def _next_group(self):
+        """Form the next batch.  Everything already queued joins it.  While the GPU
+        has no free slot, waiting costs nothing, so arrivals keep being absorbed
+        until one opens.  Once a slot is free the batch launches at once, unless the
+        model asks for a queue delay or the arrivals look like a burst (see
+        ``burst_gap_s``): then it waits that long, at most, for more requests.  An
+        idle GPU never sits on a lone request of a serial client."""
         first = self._held or self.q.get()
         self._held = None
         if first is None:
             return None
         group, total = [first], first.batch
-        deadline = time.perf_counter() + self.delay_s
+        t_first = time.perf_counter()
+        deadline = t_first + self.delay_s
         have_slot = False
         while total < self.max_batch:
             try:
-                remaining = deadline - time.perf_counter()
-                nxt = self.q.get_nowait() if remaining <= 0 else self.q.get(timeout=remaining)
+                nxt = self.q.get_nowait()
             except queue.Empty:
-                # the queue delay has passed: launch as soon as the GPU has room,
-                # and keep absorbing requests that arrive while it does not
-                if have_slot or self._inflight.acquire(timeout=0.0005):
-                    have_slot = True
+                if not have_slot:
+                    have_slot = self._inflight.acquire(blocking=False)
+                if not have_slot:
+                    # GPU full: block on the slot (short timeout so arrivals are still absorbed)
+                    have_slot = self._inflight.acquire(timeout=0.0005)
+                    continue
+                done_ns, done_requests = self._last_done
+                if (group[-1].gap_ns < self.burst_gap_s * 1e9
+                        or (len(group) < done_requests
+                            and time.perf_counter_ns() - done_ns < self.burst_gap_s * 1e9)):
+                    # part of a burst, or the first requests coming back after a batch of
+                    # several was answered: more is about to arrive
+                    deadline = max(deadline, t_first + self.burst_window_s)
+                remaining = deadline - time.perf_counter()
+                if remaining <= 0:
                     break
-                continue
+                try:
+                    nxt = self.q.get(timeout=remaining)
+                except queue.Empty:
+                    break
             if nxt is None:
                 self._stop = True
                 break
@@ -343,6 +383,7 @@ class DynamicBatcher:
             event.synchronize()
             self._inflight.release()
             t_done = time.perf_counter_ns()
+            self._last_done = (t_done, len(pending))  # closed-loop clients send this many again shortly
             out_specs = {t.name: t for t in self.model.outputs}
             for it, dev_inputs, result in pending:
                 try:
