@@ -205,7 +205,9 @@ class _HttpProtocol(asyncio.Protocol):
             body = bytes(self.buf[end + 4: total])
             del self.buf[:total]
             self.busy = True
-            asyncio.ensure_future(self._handle(method, target, headers, body))
+            task = asyncio.ensure_future(self._handle(method, target, headers, body))
+            self.front.tasks.add(task)
+            task.add_done_callback(self.front.tasks.discard)
 
     async def _handle(self, method, target, headers, body):
         keep = headers.get("connection", "").lower() != "close"
@@ -246,6 +248,7 @@ class HttpFront:
         self.host = host
         self.port = port
         self._tls = tls  # (certificate chain, private key, client CA or None) as PEM file paths
+        self.tasks = set()  # requests being handled: drained (then cancelled) at shutdown
         self.pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="tca-http-srv")
         self.server = None
 
@@ -266,10 +269,17 @@ class HttpFront:
         self.port = self.server.sockets[0].getsockname()[1]
         return self.port
 
-    async def stop(self):
+    async def stop(self, grace=1.0):
         if self.server is not None:
             self.server.close()
             await self.server.wait_closed()
+        pending = [t for t in self.tasks if not t.done()]
+        if pending:  # let requests in flight finish, then drop what is still stuck
+            _, late = await asyncio.wait(pending, timeout=grace)
+            for t in late:
+                t.cancel()
+            if late:
+                await asyncio.gather(*late, return_exceptions=True)
         self.pool.shutdown(wait=False)
 
     # ------------------------------------------------------------- routing
