@@ -11,6 +11,11 @@
 // The callbacks run on the front's reactor threads with the GIL held:
 //   on_unary(call, method, request_bytes), on_stream_message(call, method,
 //   request_bytes), on_stream_end(call), on_cancel(call).
+// A large ModelInfer request (tensors on the wire) is not copied into Python
+// objects: on_unary(call, method, head_bytes, blob, spans) gets the request
+// WITHOUT its raw_input_contents entries as `head_bytes`, the whole message as
+// `blob` (a buffer-protocol object that owns the bytes) and `spans`, the
+// (offset, length) of every raw_input_contents entry inside the blob, in order.
 // They must not block: answers are produced later through reply / send /
 // finish from whichever thread completes the request.
 #define PY_SSIZE_T_CLEAN
@@ -18,6 +23,8 @@
 
 #include <set>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "tca/grpc_server.h"
 
@@ -31,6 +38,94 @@ struct PyGrpcFront {
   PyObject* on_stream_end;
   PyObject* on_cancel;
 };
+
+// Owns one received message and exposes it through the buffer protocol, so numpy
+// arrays can alias tensor bytes without a copy made under the GIL.
+struct PyBlob {
+  PyObject_HEAD
+  std::string* data;
+};
+
+int BlobGetBuffer(PyObject* self_obj, Py_buffer* view, int flags) {
+  auto* self = reinterpret_cast<PyBlob*>(self_obj);
+  return PyBuffer_FillInfo(view, self_obj, &(*self->data)[0], static_cast<Py_ssize_t>(self->data->size()),
+                           /*readonly=*/0, flags);
+}
+
+void BlobDealloc(PyObject* self_obj) {
+  auto* self = reinterpret_cast<PyBlob*>(self_obj);
+  delete self->data;
+  Py_TYPE(self_obj)->tp_free(self_obj);
+}
+
+Py_ssize_t BlobLength(PyObject* self_obj) {
+  return static_cast<Py_ssize_t>(reinterpret_cast<PyBlob*>(self_obj)->data->size());
+}
+
+PyBufferProcs kBlobBuffer = {BlobGetBuffer, nullptr};
+PySequenceMethods kBlobSequence = {BlobLength, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wmissing-field-initializers"
+PyTypeObject kBlobType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+#pragma GCC diagnostic pop
+
+constexpr size_t kZeroCopyThreshold = 128 * 1024;  // below this a plain bytes copy is cheaper than the bookkeeping
+constexpr uint32_t kRawInputContentsField = 7;     // ModelInferRequest.raw_input_contents
+
+// Splits a serialized ModelInferRequest into the message without its
+// raw_input_contents entries (`head`) and the (offset, length) of every such
+// entry.  False when the bytes are not a well-formed protobuf message (the caller
+// then hands the whole message to Python, whose parser reports the error).
+bool SplitRawContents(const std::string& msg, std::string* head, std::vector<std::pair<size_t, size_t>>* spans) {
+  const auto* p = reinterpret_cast<const uint8_t*>(msg.data());
+  const size_t n = msg.size();
+  size_t i = 0;
+  auto varint = [&](uint64_t* out) {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64 && i < n; shift += 7) {
+      const uint8_t b = p[i++];
+      v |= static_cast<uint64_t>(b & 0x7F) << shift;
+      if (!(b & 0x80)) {
+        *out = v;
+        return true;
+      }
+    }
+    return false;
+  };
+  while (i < n) {
+    const size_t start = i;
+    uint64_t tag = 0, len = 0;
+    if (!varint(&tag)) return false;
+    const uint32_t field = static_cast<uint32_t>(tag >> 3);
+    switch (tag & 7) {
+      case 0:
+        if (!varint(&len)) return false;
+        break;
+      case 1:
+        if (n - i < 8) return false;
+        i += 8;
+        break;
+      case 5:
+        if (n - i < 4) return false;
+        i += 4;
+        break;
+      case 2:
+        if (!varint(&len) || len > n - i) return false;
+        if (field == kRawInputContentsField) {
+          spans->emplace_back(i, static_cast<size_t>(len));
+          i += static_cast<size_t>(len);
+          continue;  // not part of the head
+        }
+        i += static_cast<size_t>(len);
+        break;
+      default:
+        return false;
+    }
+    head->append(msg, start, i - start);
+  }
+  return true;
+}
 
 void CallPython(PyObject* fn, const char* fmt, ...) {
   if (fn == nullptr || fn == Py_None) return;
@@ -87,6 +182,36 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   self->on_cancel = on_cancel;
   tca::server::GrpcServerFront::Handlers h;
   h.on_unary = [self](uint64_t call, const std::string& method, std::string&& request) {
+    if (request.size() >= kZeroCopyThreshold && method == "ModelInfer") {
+      std::string head;
+      std::vector<std::pair<size_t, size_t>> spans;
+      if (SplitRawContents(request, &head, &spans) && !spans.empty()) {
+        PyGILState_STATE gil = PyGILState_Ensure();
+        auto* blob = PyObject_New(PyBlob, &kBlobType);
+        PyObject* list = blob ? PyTuple_New(static_cast<Py_ssize_t>(spans.size())) : nullptr;
+        if (blob != nullptr && list != nullptr) {
+          blob->data = new std::string(std::move(request));
+          for (size_t k = 0; k < spans.size(); ++k)
+            PyTuple_SET_ITEM(list, static_cast<Py_ssize_t>(k),
+                             Py_BuildValue("(nn)", static_cast<Py_ssize_t>(spans[k].first),
+                                           static_cast<Py_ssize_t>(spans[k].second)));
+          PyObject* result = PyObject_CallFunction(self->on_unary, "Ksy#OO", static_cast<unsigned long long>(call),
+                                                   method.c_str(), head.data(), static_cast<Py_ssize_t>(head.size()),
+                                                   reinterpret_cast<PyObject*>(blob), list);
+          if (result == nullptr) PyErr_WriteUnraisable(self->on_unary);
+          else Py_DECREF(result);
+        } else {
+          PyErr_Clear();
+        }
+        Py_XDECREF(list);
+        if (blob != nullptr) {
+          if (list == nullptr) blob->data = new std::string();  // allocation failed before ownership moved
+          Py_DECREF(reinterpret_cast<PyObject*>(blob));
+        }
+        PyGILState_Release(gil);
+        return;
+      }
+    }
     CallPython(self->on_unary, "(Ksy#)", static_cast<unsigned long long>(call), method.c_str(), request.data(),
                static_cast<Py_ssize_t>(request.size()));
   };
@@ -204,6 +329,14 @@ extern "C" int tca_register_grpc_front(PyObject* module) {
   kFrontType.tp_dealloc = FrontDealloc;
   kFrontType.tp_methods = kFrontMethods;
   if (PyType_Ready(&kFrontType) < 0) return -1;
+  kBlobType.tp_name = "_tca_pyext.Blob";
+  kBlobType.tp_basicsize = sizeof(PyBlob);
+  kBlobType.tp_flags = Py_TPFLAGS_DEFAULT;
+  kBlobType.tp_doc = "One received message; exposes its bytes through the buffer protocol.";
+  kBlobType.tp_dealloc = BlobDealloc;
+  kBlobType.tp_as_buffer = &kBlobBuffer;
+  kBlobType.tp_as_sequence = &kBlobSequence;
+  if (PyType_Ready(&kBlobType) < 0) return -1;
   Py_INCREF(&kFrontType);
   if (PyModule_AddObject(module, "GrpcFront", reinterpret_cast<PyObject*>(&kFrontType)) < 0) {
     Py_DECREF(&kFrontType);

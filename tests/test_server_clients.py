@@ -579,3 +579,29 @@ def test_both_grpc_fronts_serve_the_same_surface(impl):
                 got.append(int(result.as_numpy("OUT")[0]))
             c.stop_stream()
             assert got == list(range(n))
+
+
+def test_large_wire_tensors_take_the_zero_copy_path():
+    """Requests above the native front's zero-copy threshold: tensors stay in the
+    transport buffer and are aliased by numpy; answers must be bit-identical,
+    also for several inputs, BYTES data and a malformed message."""
+    import tritonclient.grpc as g
+    from triton_client_amd.server import Server
+
+    with Server(models=["simple", "custom_identity_int32", "simple_identity"], grpc_impl="native") as srv:
+        with g.InferenceServerClient(srv.grpc_url) as c:
+            x = np.arange(200_000, dtype=np.int32).reshape(1, -1)  # 800 KB
+            inp = g.InferInput("INPUT0", list(x.shape), "INT32").set_data_from_numpy(x)
+            for _ in range(3):
+                out = c.infer("custom_identity_int32", [inp]).as_numpy("OUTPUT0")
+                np.testing.assert_array_equal(out, x)
+            # BYTES payload above the threshold
+            s = np.array([[b"x" * 300_000, b"tail"]], dtype=np.object_)
+            sin = g.InferInput("INPUT0", [1, 2], "BYTES").set_data_from_numpy(s)
+            got = c.infer("simple_identity", [sin]).as_numpy("OUTPUT0")
+            assert got.shape == (1, 2) and got[0, 0] == s[0, 0] and got[0, 1] == b"tail"
+            # wrong byte count is still reported cleanly
+            bad = g.InferInput("INPUT0", [1, 16], "INT32")
+            bad._raw_content = b"\0" * 200_000
+            with pytest.raises(InferenceServerException, match="byte size"):
+                c.infer("custom_identity_int32", [bad])

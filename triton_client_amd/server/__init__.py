@@ -29,7 +29,7 @@ class Server:
 
     def __init__(self, models=None, gpu=None, http_port=0, grpc_port=0, host="127.0.0.1", model_control="none",
                  enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32, grpc_impl=None,
-                 tls_cert=None, tls_key=None, tls_client_ca=None):
+                 tls_cert=None, tls_key=None, tls_client_ca=None, grpc_reactors=None):
         self.core = InferenceCore(models=models, gpu=gpu, model_control=model_control)
         self.host = host
         self._http_port = http_port
@@ -44,6 +44,8 @@ class Server:
         # TLS on both fronts when a certificate + key (PEM files) are given; `tls_client_ca`
         # additionally requires client certificates signed by that CA (mutual TLS)
         self._tls = (tls_cert, tls_key, tls_client_ca) if tls_cert and tls_key else None
+        # epoll reactor threads of the native gRPC front (each owns the connections it accepted)
+        self._grpc_reactors = int(grpc_reactors or os.environ.get("TCA_GRPC_REACTORS") or 2)
         self._loop = None
         self._thread = None
         self.http = None
@@ -63,7 +65,7 @@ class Server:
                 from .native_grpc_front import NativeGrpcFront
 
                 self.grpc = NativeGrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers,
-                                            tls=self._tls)
+                                            reactors=self._grpc_reactors, tls=self._tls)
             elif self._grpc_impl == "grpcio":
                 from .grpc_front import GrpcFront
 

@@ -40,12 +40,15 @@ def _param_value(p):
     return getattr(p, kind) if kind else None
 
 
-def request_from_proto(msg, streaming=False):
-    """``ModelInferRequest`` -> :class:`InferRequest`."""
+def request_from_proto(msg, streaming=False, raw=None):
+    """``ModelInferRequest`` -> :class:`InferRequest`.  ``raw`` replaces the
+    message's ``raw_input_contents`` (buffers a transport kept out of the parsed
+    message to avoid copying them)."""
     req = InferRequest(model_name=msg.model_name, model_version=msg.model_version, id=msg.id, streaming=streaming,
                        parameters={k: _param_value(v) for k, v in msg.parameters.items()})
-    raw_iter = iter(msg.raw_input_contents)
-    use_raw = len(msg.raw_input_contents) > 0
+    raw_contents = msg.raw_input_contents if raw is None else raw
+    raw_iter = iter(raw_contents)
+    use_raw = len(raw_contents) > 0
     for t in msg.inputs:
         it = InputTensor(name=t.name, datatype=t.datatype, shape=list(t.shape))
         params = {k: _param_value(v) for k, v in t.parameters.items()}
@@ -60,6 +63,8 @@ def request_from_proto(msg, streaming=False):
                     f"'{msg.model_name}'")
             try:
                 it.raw = next(raw_iter)
+                if t.datatype == "BYTES" and not isinstance(it.raw, bytes):
+                    it.raw = bytes(it.raw)  # the length-prefix decoder works on bytes
             except StopIteration:
                 raise ServerError(
                     f"expected raw_input_contents for every non shared-memory input of model '{msg.model_name}'"

@@ -82,9 +82,9 @@ class NativeGrpcFront:
             self._prof = cProfile.Profile()
             lock = threading.Lock()
 
-            def on_unary(call, method, data, _inner=self._on_unary):
+            def on_unary(call, method, data, blob=None, spans=None, _inner=self._on_unary):
                 with lock:
-                    self._prof.runcall(_inner, call, method, data)
+                    self._prof.runcall(_inner, call, method, data, blob, spans)
 
         kwargs = {}
         if tls:  # (certificate chain, private key, client CA or None) as PEM file paths
@@ -108,10 +108,16 @@ class NativeGrpcFront:
         return self._front.stats()
 
     # ------------------------------------------------------------------ unary
-    def _on_unary(self, call, method, data):
+    def _on_unary(self, call, method, data, blob=None, spans=None):
         if method == "ModelInfer":
             try:
-                req = request_from_proto(pb.ModelInferRequest.FromString(data))
+                raw = None
+                if blob is not None:
+                    # large request: `data` is the message without its tensors, which stay in
+                    # the C++ buffer and are aliased, not copied
+                    whole = memoryview(blob)
+                    raw = [whole[off: off + size] for off, size in spans]
+                req = request_from_proto(pb.ModelInferRequest.FromString(data), raw=raw)
             except ServerError as e:
                 self._front.finish(call, _STATUS.get(e.code, _INTERNAL), e.message)
                 return
