@@ -132,9 +132,14 @@ __global__ __launch_bounds__(kThreads) void BytesIndexKernel(const uint8_t* __re
         if (cnt >= max_elems || cur == size) { state = 1; break; }
         if (cur + 4 > size) { state = 2; break; }
         if (cur + 4 > end) break;  // prefix straddles the chunk: restage from cur
+        // The walk is one dependent LDS read per element: fetch the (unaligned) prefix as
+        // the two aligned dwords around it - they issue together, one LDS latency - instead
+        // of four byte reads.
         const uint32_t rel = static_cast<uint32_t>(cur - base);
-        const uint32_t len = static_cast<uint32_t>(lds[rel]) | (static_cast<uint32_t>(lds[rel + 1]) << 8) |
-                             (static_cast<uint32_t>(lds[rel + 2]) << 16) | (static_cast<uint32_t>(lds[rel + 3]) << 24);
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(lds + (rel & ~3u));
+        const uint32_t lo = words[0], hi = words[1];
+        const uint32_t shift = (rel & 3u) * 8u;
+        const uint32_t len = shift ? (lo >> shift) | (hi << (32u - shift)) : lo;
         if (len > size - (cur + 4)) { state = 2; break; }
         offsets[cnt] = cur + 4;
         lens[cnt] = len;
