@@ -345,6 +345,30 @@ int tca_hipshm_copy_from(void* handle, uint64_t offset, const void* src, uint64_
   return 0;
 }
 
+// Same as tca_hipshm_copy_from for device sources, but only ENQUEUES the copy on the
+// caller's stream (created on the SOURCE device): several of these towards different
+// peer GPUs run concurrently, one xGMI link each.  The caller synchronises the stream.
+int tca_hipshm_copy_from_async(void* handle, uint64_t offset, const void* src, uint64_t n, int src_device,
+                               void* stream) {
+  auto* r = static_cast<Region*>(handle);
+  if (!r) return FailMsg("null region");
+  int rc = CheckRange(r, offset, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (r->fake) { std::memcpy(static_cast<char*>(r->ptr) + offset, src, n); return 0; }
+  if (src_device < 0) return FailMsg("asynchronous copies need a device (or pinned) source");
+  DeviceGuard guard(src_device);
+  if (src_device != r->device) {
+    int can = 0;
+    (void)hipDeviceCanAccessPeer(&can, src_device, r->device);
+    if (can) (void)hipDeviceEnablePeerAccess(r->device, 0);  // already-enabled is fine
+    (void)hipGetLastError();
+  }
+  HIP_TRY(hipMemcpyAsync(static_cast<char*>(r->ptr) + offset, src, n, hipMemcpyDefault, static_cast<hipStream_t>(stream)),
+          "hipMemcpyAsync(peer)");
+  return 0;
+}
+
 int tca_hipshm_destroy(void* handle) {
   auto* r = static_cast<Region*>(handle);
   if (!r) return FailMsg("null region");

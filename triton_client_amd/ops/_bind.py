@@ -48,6 +48,8 @@ def install(lib):
     lib.tca_hipshm_read.argtypes = [c_void_p, c_uint64, c_void_p, c_uint64]
     lib.tca_hipshm_copy_from.restype = c_int
     lib.tca_hipshm_copy_from.argtypes = [c_void_p, c_uint64, c_void_p, c_uint64, c_int]
+    lib.tca_hipshm_copy_from_async.restype = c_int
+    lib.tca_hipshm_copy_from_async.argtypes = [c_void_p, c_uint64, c_void_p, c_uint64, c_int, c_void_p]
     lib.tca_hipshm_destroy.restype = c_int
     lib.tca_hipshm_destroy.argtypes = [c_void_p]
     lib.tca_hipshm_open.restype = c_int
