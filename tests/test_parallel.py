@@ -188,3 +188,62 @@ def test_direct_peer_exchange_host_backed(world, batch):
 def test_direct_peer_exchange_hip_ipc():
     """Real hipIpc mappings and device-to-device copies: three ranks sharing GPU 0."""
     _run_direct(3, 16, 0)
+
+
+def test_sharded_client_sequences_and_streams():
+    """Sequence affinity (state stays on one endpoint) and one stream per endpoint
+    for sequences and a decoupled model."""
+    import queue
+
+    import tritonclient.grpc as g
+    from triton_client_amd.models import DEFAULT_CPU_MODELS
+    from triton_client_amd.parallel import ShardedClient
+    from triton_client_amd.server import Server
+
+    servers = [Server(models=DEFAULT_CPU_MODELS).start() for _ in range(3)]
+    try:
+        with ShardedClient([s.grpc_url for s in servers], protocol="grpc") as sc:
+            # unary sequences: the server rejects a non-START request for a sequence it has not
+            # seen, so any request routed away from the sequence's endpoint fails
+            def seq_input(v):
+                return [g.InferInput("INPUT", [1, 1], "INT32").set_data_from_numpy(np.array([[v]], dtype=np.int32))]
+
+            totals = {}
+            for sid in (101, 202, 303, 404, 505):
+                for k, v in enumerate((1, 2, 3, 4)):
+                    r = sc.infer("simple_sequence", seq_input(v), sequence_id=sid, sequence_start=k == 0,
+                                 sequence_end=k == 3)
+                    totals.setdefault(sid, []).append(int(r.as_numpy("OUTPUT")[0, 0]))
+            assert all(t == [2, 2, 3, 4] for t in totals.values()), totals  # +1 on the first request
+            assert sum(1 for n in sc.sent if n) >= 2, "five sequence ids should land on more than one endpoint"
+
+            # streams: interleaved sequences + a decoupled model over per-endpoint streams
+            got = queue.Queue()
+            sc.start_stream(callback=lambda result, error: got.put((result, error)))
+            for k, v in enumerate((5, 6, 7)):
+                for sid in ("alpha", "beta", "gamma"):
+                    sc.async_stream_infer("simple_sequence", seq_input(v), sequence_id=sid, sequence_start=k == 0,
+                                          sequence_end=k == 2, request_id=f"{sid}_{k}")
+            finals = {}
+            for _ in range(9):
+                result, error = got.get(timeout=30)
+                assert error is None, error
+                rid = result.get_response().id
+                finals[rid] = int(result.as_numpy("OUTPUT")[0, 0])
+            assert all(finals[f"{sid}_0"] == 6 and finals[f"{sid}_2"] == 7 for sid in ("alpha", "beta", "gamma")), finals
+
+            n = 6
+            rep = [g.InferInput("IN", [n], "INT32").set_data_from_numpy(np.arange(n, dtype=np.int32)),
+                   g.InferInput("DELAY", [n], "UINT32").set_data_from_numpy(np.zeros(n, dtype=np.uint32)),
+                   g.InferInput("WAIT", [1], "UINT32").set_data_from_numpy(np.zeros(1, dtype=np.uint32))]
+            used = {sc.async_stream_infer("repeat_int32", rep, request_id=f"rep{j}") for j in range(3)}
+            values = []
+            for _ in range(3 * n):
+                result, error = got.get(timeout=30)
+                assert error is None, error
+                values.append(int(result.as_numpy("OUT")[0]))
+            assert sorted(values) == sorted(list(range(n)) * 3) and len(used) == 3
+            sc.stop_stream()
+    finally:
+        for s in servers:
+            s.stop()

@@ -4,6 +4,11 @@
 dead; ``ShardedClient`` wraps N protocol clients behind the single-client
 ``infer`` signature, retries a failed request on another endpoint and
 periodically probes dead endpoints so that a restarted GPU worker rejoins.
+Requests of a stateful sequence (``sequence_id``) always go to the endpoint the
+id hashes to - the sequence state lives in that server - and the streaming API
+(``start_stream`` / ``async_stream_infer`` / ``stop_stream``, gRPC) keeps one
+bidirectional stream per endpoint, so decoupled models and interleaved
+sequences scale over the GPUs the same way unary requests do.
 
 Reference hook: the Java client's endpoint provider that never returns the same
 endpoint twice in a row during retries
@@ -87,7 +92,20 @@ class ShardedClient:
         self.retries = retries
         self.sent = [0] * len(urls)
 
+    def _home(self, sequence_id):
+        """Endpoint index that owns a sequence (stable for the life of the client)."""
+        import zlib
+
+        return zlib.crc32(str(sequence_id).encode("utf-8")) % len(self.clients)
+
     def infer(self, model_name, inputs, **kwargs):
+        seq = kwargs.get("sequence_id", 0)
+        if seq not in (0, "", None):
+            # stateful: no failover, the state cannot follow the request
+            i = self._home(seq)
+            result = self.clients[i].infer(model_name, inputs, **kwargs)
+            self.sent[i] += 1
+            return result
         tried = []
         last = None
         for _ in range(self.retries + 1):
@@ -106,6 +124,34 @@ class ShardedClient:
                 self.pool.mark_dead(i)
                 last = e
         raise last or InferenceServerException("no live endpoint available")
+
+    # ------------------------------------------------------------- streaming
+    def start_stream(self, callback, **kwargs):
+        """One bidirectional stream per endpoint; ``callback(result, error)`` receives
+        the responses of all of them (from the endpoints' reader threads)."""
+        for c in self.clients:
+            c.start_stream(callback=callback, **kwargs)
+        self._streaming = True
+
+    def async_stream_infer(self, model_name, inputs, **kwargs):
+        seq = kwargs.get("sequence_id", 0)
+        if seq not in (0, "", None):
+            i = self._home(seq)
+        else:
+            i = self.pool.acquire()
+            if i is None:
+                raise InferenceServerException("no live endpoint available")
+        self.clients[i].async_stream_infer(model_name, inputs, **kwargs)
+        self.sent[i] += 1
+        return i
+
+    def stop_stream(self, **kwargs):
+        for c in self.clients:
+            try:
+                c.stop_stream(**kwargs)
+            except Exception:
+                pass
+        self._streaming = False
 
     def live_endpoints(self):
         return self.pool.alive()
