@@ -140,3 +140,23 @@ def test_gpu_metrics_sampling(two_servers, tmp_path, monkeypatch):
     rows = _run(["-m", "simple", "-u", a.grpc_url, "--concurrency-range", "2", "-p", "400", "--warmup-ms", "50", "-r",
                  "3", "-s", "60", "--stability-windows", "2", "--worker-processes", "1", "--gpu-metrics"])
     assert rows[0]["gpu_util_pct"] == 70.0 and rows[0]["gpu_power_w"] == 400.0 and rows[0]["gpu_mem_pct"] == 20.0
+
+
+def test_dead_endpoint_is_dropped_and_load_resharded():
+    """A sweep over two endpoints keeps going on the survivor after one dies."""
+    from triton_client_amd import _build
+    from triton_client_amd.models import DEFAULT_CPU_MODELS
+    from triton_client_amd.server import Server
+
+    _build.build_cpp()
+    a = Server(models=DEFAULT_CPU_MODELS).start()
+    b = Server(models=DEFAULT_CPU_MODELS).start()
+    try:
+        urls = f"{a.grpc_url},{b.grpc_url}"
+        b.stop()
+        for extra in (["--native"], ["--worker-processes", "1", "-r", "3", "-s", "60"]):
+            rows = _run(["-m", "simple", "--urls", urls, "--concurrency-range", "2", "-p", "200",
+                         "--stability-windows", "2", "--warmup-ms", "50"] + extra)
+            assert rows[0]["errors"] == 0 and rows[0]["requests"] > 10
+    finally:
+        a.stop()
