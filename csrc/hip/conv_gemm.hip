@@ -50,6 +50,7 @@ namespace {
 
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half4 = __attribute__((ext_vector_type(4))) _Float16;
+using ushort8 = __attribute__((ext_vector_type(8))) unsigned short;
 using float4v = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kThreads = 256;
@@ -473,6 +474,210 @@ __global__ __launch_bounds__(kThreads) void BiasReluMaxPoolKernel(const _Float16
   }
 }
 
+// ---------------------------------------------------------------------------
+// Network stem in ONE kernel: 7x7 stride-2 pad-3 convolution over 3 input
+// channels + bias + ReLU + 3x3 stride-2 pad-1 max pooling.
+//
+//   x   [B][3][H][W]   fp16, plain NCHW - the layout clients send, so no layout
+//                      conversion pass in front of the network
+//   wk  [64][192]      fp16 weights with K ordered (c, kh, kw8): kw padded 7 -> 8
+//                      with the zero in FRONT (kw8 = kw + 1) and K padded 168 -> 192
+//                      with zeros, so that the 8 K values one MFMA lane feeds are 8
+//                      CONSECUTIVE input pixels of one input row (one (c, kh) pair)
+//                      starting at an EVEN column: aligned dword reads end to end
+//   y   [B][PH][PW][64] fp16 NHWC, the pooled activation
+//
+// A block produces an 8x8 tile of pooled pixels for all 64 channels.  That needs
+// a 17x17 tile of convolution outputs, which needs a 39x39 patch of each input
+// plane: the patch is staged in LDS once (zero filled outside the image), the
+// whole weight matrix lives in registers as MFMA A fragments (24 fragments per
+// lane), and every group of 16 convolution pixels is 6 K steps x 4 channel
+// fragments of v_mfma_f32_16x16x32_f16 whose B fragments are read straight from
+// the patch.  Bias + ReLU are applied on the accumulators, the convolution tile
+// goes to LDS as fp16 and the pooled maxima are written with 16-byte stores.
+// The full-resolution convolution output (205 MB at batch 128) never exists in
+// memory.  Post-ReLU values are >= 0, so pooling's padding can be treated as 0.
+constexpr int kStemPool = 8;                       // pooled tile edge
+constexpr int kStemConv = 2 * kStemPool + 1;       // 17 convolution rows / columns
+constexpr int kStemPixels = kStemConv * kStemConv; // 289
+constexpr int kStemGroups = (kStemPixels + 15) / 16;  // 19 groups of 16 pixels
+constexpr int kStemPatch = 2 * (kStemConv - 1) + 7;   // 39 input rows / columns
+constexpr int kStemPatchPitch = 40;                // halfs per patch row (column 39 is the kw padding)
+constexpr int kStemPatchHalfs = 3 * kStemPatch * kStemPatchPitch;
+constexpr int kStemConvPitch = 72;                 // halfs per convolution pixel in LDS (16-byte aligned rows)
+constexpr int kStemK = 192;
+
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void StemConvPoolKernel(const _Float16* __restrict__ x,
+                                                               const _Float16* __restrict__ wk,
+                                                               const _Float16* __restrict__ bias,
+                                                               _Float16* __restrict__ y, int H, int W, int OH, int OW,
+                                                               int PH, int PW, int tiles_w, int tiles_per_image,
+                                                               int total_tiles, unsigned x_bytes) {
+  __shared__ __attribute__((aligned(16))) _Float16 patch[kStemPatchHalfs + 16];  // + 16 zero halfs for the K padding
+  __shared__ __attribute__((aligned(16))) _Float16 conv[kStemGroups * 16 * kStemConvPitch];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // Loaded ONCE per block (blocks are persistent over tiles): the weight matrix as MFMA A
+  // fragments, lane -> (channel ni*16 + lane&15, k = 32 s + 8 (lane>>4) ..+7)
+  half8 wf[4][6];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+      wf[ni][s] = *reinterpret_cast<const half8*>(wk + (ni * 16 + (lane & 15)) * kStemK + s * 32 + (lane >> 4) * 8);
+  // K chunk (8 values) of this lane in step s: chunk = 4 s + lane>>4 -> (c, kh); chunks 21..23 are padding
+  int chunk_off[6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int chunk = 4 * s + (lane >> 4);
+    const int c = chunk / 7, kh = chunk - c * 7;
+    chunk_off[s] = chunk < 21 ? (c * kStemPatch + kh) * kStemPatchPitch : -1;
+  }
+  half4 b[4];  // kept packed (8 registers), widened at use
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const half4*>(bias + ni * 16 + (lane >> 4) * 4);
+  if (tid < 16) patch[kStemPatchHalfs + tid] = static_cast<_Float16>(0);
+
+  constexpr int kRowDwords = kStemPatchPitch / 2;    // 20 aligned dwords per patch row
+  constexpr int kRowStep = kThreads / kRowDwords;    // 12 rows per pass of the block
+  constexpr int kLoadIters = (3 * kStemPatch + kRowStep - 1) / kRowStep;  // 10 passes cover the 117 rows
+
+  // Patch rows of tile `tile_id` as aligned dwords into registers (zeros outside the image;
+  // W is even, so a dword is inside or outside as a whole).  Issued one tile AHEAD, so the
+  // loads are in flight while the current tile computes.
+  // Thread -> (patch row row0 + kRowStep * it, dword column j): the column is fixed per
+  // thread and the row advances by a constant, so a tile costs a handful of VALU
+  // instructions per load; out-of-image dwords are zero-filled by the buffer range check
+  // (no divergent branches around the loads).
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(x), 0, static_cast<int>(x_bytes), 0x00020000);
+  uint32_t staged[kLoadIters];
+  const int load_j = tid % kRowDwords;
+  const int load_row0 = tid / kRowDwords;  // 0 .. kRowStep (threads past 20 * kRowStep idle along)
+  auto fetch_patch = [&](int tile_id) {
+    const int img = tile_id / tiles_per_image;
+    const int tile = tile_id - img * tiles_per_image;
+    const int ty = tile / tiles_w;
+    const int tx = tile - ty * tiles_w;
+    const int ih0 = 4 * ty * kStemPool - 5;  // input row at patch row 0
+    const int iw0 = 4 * tx * kStemPool - 6;  // input column at patch column 0: EVEN (one left of the first tap;
+                                             // that column meets the zero weight of the kw padding)
+    const int img_bytes = img * 3 * H * W * 2;  // wave-uniform: rides in the scalar offset of the load
+    const int iw = iw0 + 2 * load_j;
+    // validity as integer masks and a branch-free select: the compiler must not wrap the
+    // loads in divergent control flow
+    const unsigned col_ok = static_cast<unsigned>(static_cast<unsigned>(iw) < static_cast<unsigned>(W)) &
+                            static_cast<unsigned>(load_row0 < kRowStep);
+#pragma unroll
+    for (int it = 0; it < kLoadIters; ++it) {
+      const int rc = load_row0 + it * kRowStep;  // c * 39 + r
+      const int c = static_cast<int>(rc >= kStemPatch) + static_cast<int>(rc >= 2 * kStemPatch);
+      const int r = rc - c * kStemPatch;
+      const int ih = ih0 + r;
+      const unsigned ok = col_ok & static_cast<unsigned>(rc < 3 * kStemPatch) &
+                          static_cast<unsigned>(static_cast<unsigned>(ih) < static_cast<unsigned>(H));
+      // out-of-image dwords get an all-ones offset, past the descriptor: the range check returns zero
+      const unsigned off = static_cast<unsigned>(((c * H + ih) * W + iw) * 2) | (ok - 1u);
+      staged[it] = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, static_cast<int>(off), img_bytes, 0));
+    }
+  };
+
+  if (static_cast<int>(blockIdx.x) < total_tiles) fetch_patch(blockIdx.x);
+  for (int tile_id = blockIdx.x; tile_id < total_tiles; tile_id += gridDim.x) {
+    const int img = tile_id / tiles_per_image;
+    const int tile = tile_id - img * tiles_per_image;
+    const int ty = tile / tiles_w;
+    const int tx = tile - ty * tiles_w;
+    const int ph0 = ty * kStemPool, pw0 = tx * kStemPool;
+    const int oh0 = 2 * ph0 - 1, ow0 = 2 * pw0 - 1;  // convolution pixel at tile position (0, 0)
+    if (load_row0 < kRowStep) {
+#pragma unroll
+      for (int it = 0; it < kLoadIters; ++it) {
+        const int rc = load_row0 + it * kRowStep;
+        if (rc < 3 * kStemPatch) reinterpret_cast<uint32_t*>(patch)[rc * kRowDwords + load_j] = staged[it];
+      }
+    }
+    __syncthreads();
+    if (tile_id + static_cast<int>(gridDim.x) < total_tiles) fetch_patch(tile_id + gridDim.x);
+
+    for (int g = wave; g < kStemGroups; g += kThreads / 64) {
+      const int q = g * 16 + (lane & 15);
+      const int qc = q < kStemPixels ? q : kStemPixels - 1;  // the last group is ragged: recompute a valid pixel
+      const int r = qc / kStemConv;
+      const int cx = qc - r * kStemConv;
+      const int pix_off = 2 * r * kStemPatchPitch + 2 * cx;
+      float4v acc[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        const int off = chunk_off[s] >= 0 ? chunk_off[s] + pix_off : kStemPatchHalfs;
+        // 8 consecutive input pixels starting at an even half index, i.e. 4-byte aligned
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(patch + off);
+        union {
+          uint32_t u[4];
+          half8 h;
+        } frag;
+        frag.u[0] = src[0];
+        frag.u[1] = src[1];
+        frag.u[2] = src[2];
+        frag.u[3] = src[3];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni][s], frag.h, acc[ni], 0, 0, 0);
+      }
+      // D^T layout: lane holds pixel q and channels ni*16 + 4 (lane>>4) .. +3
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        half4 packed;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float f = acc[ni][k] + static_cast<float>(b[ni][k]);
+          packed[k] = static_cast<_Float16>(f > 0.f ? f : 0.f);
+        }
+        *reinterpret_cast<half4*>(conv + q * kStemConvPitch + ni * 16 + (lane >> 4) * 4) = packed;
+      }
+    }
+    __syncthreads();
+
+    // 3x3 / stride 2 / pad 1 max pooling of the tile: one thread per pooled pixel and 8
+    // channels.  Window positions outside the convolution output are clamped onto the
+    // nearest valid row / column, which lies inside the same window, so the maximum is
+    // unchanged and there is no divergent control flow.
+#pragma unroll
+    for (int pass = 0; pass < kStemPool * kStemPool * 8 / kThreads; ++pass) {
+      const int v = tid + pass * kThreads;
+      const int cv = v & 7;
+      const int pp = v >> 3;
+      const int py = pp / kStemPool, px = pp - py * kStemPool;
+      const int ph = ph0 + py, pw = pw0 + px;
+      // post-ReLU values are non-negative (+0 included), and non-negative fp16 values order
+      // like their bit patterns: an unsigned 16-bit maximum needs no NaN canonicalisation
+      ushort8 best = ushort8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        int oh = oh0 + 2 * py + dy;
+        oh = oh < 0 ? 0 : (oh > OH - 1 ? OH - 1 : oh);
+        const int r = oh - oh0;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          int ow = ow0 + 2 * px + dx;
+          ow = ow < 0 ? 0 : (ow > OW - 1 ? OW - 1 : ow);
+          const int cx = ow - ow0;
+          const ushort8 val = *reinterpret_cast<const ushort8*>(conv + (r * kStemConv + cx) * kStemConvPitch + cv * 8);
+          best = __builtin_elementwise_max(best, val);
+        }
+      }
+      if (ph < PH && pw < PW)
+        *reinterpret_cast<ushort8*>(y + ((static_cast<long long>(img) * PH + ph) * PW + pw) * 64 + cv * 8) = best;
+    }
+    // the next tile's patch may be staged right away (its readers are behind the barrier above);
+    // the convolution tile is only rewritten after the barrier that follows that staging
+  }
+}
+
 template <int BM, int BN, int kWN, bool kSpatial, bool kGlds>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, hipStream_t st) {
@@ -622,6 +827,31 @@ int tca_bias_relu_maxpool_launch(const void* x, const void* bias, void* y, int b
                      static_cast<hipStream_t>(stream), static_cast<const _Float16*>(x),
                      static_cast<const _Float16*>(bias), static_cast<_Float16*>(y), in_h, in_w, out_h, out_w,
                      channels / 8, out_vecs);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
+}
+
+// Stem: y[batch][PH][PW][64] = maxpool3x3/2(relu(conv7x7/2(x[batch][3][in_h][in_w]) + bias)); wk as documented at
+// StemConvPoolKernel ([64][192], K order (c, kh, kw padded to 8)).
+int tca_stem_conv_pool_launch(const void* x, const void* wk, const void* bias, void* y, int batch, int in_h, int in_w,
+                              void* stream) {
+  if (!x || !wk || !bias || !y || batch <= 0 || in_h < 7 || in_w < 7) return -1;
+  if (in_w % 2 != 0 || (reinterpret_cast<uintptr_t>(x) & 3) != 0) return -2;  // rows are read as aligned dwords
+  const long long x_bytes = static_cast<long long>(batch) * 3 * in_h * in_w * 2;
+  if (x_bytes >= 0x7FFFFFFFll) return -2;  // 32-bit buffer offsets
+  const int oh = (in_h + 6 - 7) / 2 + 1, ow = (in_w + 6 - 7) / 2 + 1;
+  const int ph = (oh - 1) / 2 + 1, pw = (ow - 1) / 2 + 1;
+  const int tiles_h = (ph + kStemPool - 1) / kStemPool, tiles_w = (pw + kStemPool - 1) / kStemPool;
+  const long long tiles = static_cast<long long>(batch) * tiles_h * tiles_w;
+  if (tiles > 0x7FFFFFFF) return -2;
+  // persistent blocks: three per CU (the LDS limit), each walks tiles with a grid stride and
+  // keeps the weight fragments in registers throughout
+  const long long blocks = tiles < 256 * 3 ? tiles : 256 * 3;
+  hipLaunchKernelGGL(StemConvPoolKernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const _Float16*>(x),
+                     static_cast<const _Float16*>(wk), static_cast<const _Float16*>(bias), static_cast<_Float16*>(y),
+                     in_h, in_w, oh, ow, ph, pw, tiles_w, tiles_h * tiles_w, static_cast<int>(tiles),
+                     static_cast<unsigned>(x_bytes));
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
 }

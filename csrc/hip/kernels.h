@@ -84,4 +84,9 @@ int tca_bias_act_launch(void* y, const void* bias, const void* residual, long lo
 // y[batch][oh][ow][channels] = relu(maxpool3x3/2/pad1(x[batch][in_h][in_w][channels]) + bias), fp16 NHWC, channels % 8 == 0.
 int tca_bias_relu_maxpool_launch(const void* x, const void* bias, void* y, int batch, int in_h, int in_w, int channels,
                                  void* stream);
+
+// Fused network stem (conv 7x7/2 pad 3 over 3 channels + bias + ReLU + max pool 3x3/2 pad 1).
+// x: [batch][3][in_h][in_w] fp16 NCHW; wk: [64][192] fp16 (see conv_gemm.hip); y: [batch][PH][PW][64] fp16 NHWC.
+int tca_stem_conv_pool_launch(const void* x, const void* wk, const void* bias, void* y, int batch, int in_h, int in_w,
+                              void* stream);
 }

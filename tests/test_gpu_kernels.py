@@ -364,3 +364,38 @@ def test_bias_relu_maxpool_matches_reference(torch, shape):
     ref = (pooled + bias.float().view(1, -1, 1, 1)).clamp_min(0).half()
     assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 96), (1, 37, 54), (2, 7, 10), (40, 224, 224)])
+def test_stem_conv_pool_matches_fp32_reference(torch, shape):
+    """conv 7x7/2 + bias + ReLU + max pool 3x3/2 in one kernel vs the fp32 chain,
+    including image sizes that leave ragged pooled tiles."""
+    from triton_client_amd.ops import conv
+
+    n, h, w = shape
+    gen = torch.Generator(device="cuda").manual_seed(h * w)
+    x = torch.randn(n, 3, h, w, device="cuda", generator=gen).half()
+    wt = (torch.randn(64, 3, 7, 7, device="cuda", generator=gen) / 147 ** 0.5).half()
+    bias = torch.randn(64, device="cuda", generator=gen).half()
+    got = conv.stem_conv_pool(x, conv.pack_stem_weight(wt), bias)
+    ref = torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=2, padding=3).clamp_min(0)
+    ref = torch.nn.functional.max_pool2d(ref, 3, stride=2, padding=1)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(got.float(), ref, rtol=4e-3, atol=4e-3)
+
+
+@pytest.mark.gpu
+def test_stem_conv_pool_exact_integer_taps(torch):
+    """Integer data: a wrong tap / channel order or padding rule changes exact sums."""
+    from triton_client_amd.ops import conv
+
+    x = torch.randint(-2, 3, (2, 3, 40, 46), device="cuda").half()
+    wt = torch.randint(-1, 2, (64, 3, 7, 7), device="cuda").half()
+    wt[5, 2, 6, 0] = 3.0  # asymmetric in (c, kh, kw)
+    wt[9, 0, 0, 6] = -3.0
+    bias = torch.arange(-32, 32, device="cuda").half()
+    got = conv.stem_conv_pool(x, conv.pack_stem_weight(wt), bias)
+    ref = torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=2, padding=3).clamp_min(0)
+    ref = torch.nn.functional.max_pool2d(ref, 3, stride=2, padding=1)
+    assert torch.equal(got.float(), ref)

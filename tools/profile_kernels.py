@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--resnet-batch-only", action="store_true", help="ResNet-50: only --batch instead of 8/64/128")
     ap.add_argument("--only", default="all", choices=["all", "preprocess", "codec", "classify", "resnet"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
@@ -74,7 +75,7 @@ def main():
 
         model = MODEL_ZOO["resnet50"]()
         model.load(0)
-        for b in (8, 64, 128):
+        for b in ([args.batch] if args.resnet_batch_only else (8, 64, 128)):
             x = torch.randn(b, 3, 224, 224, device=dev, dtype=torch.float16)
             out = torch.empty(b, 1000, device=dev, dtype=torch.float32)
 

@@ -180,6 +180,8 @@ class ResNet50(Model):
         self.use_graphs = True
         # hand-written fused kernels (default) vs the plain library forward
         self.fused = os.environ.get("TCA_RESNET_FUSED", "1") != "0"
+        # conv 7x7 + bias + ReLU + max pool as one kernel (A/B switch; off = library conv + fused pool pass)
+        self.fused_stem = os.environ.get("TCA_RESNET_FUSED_STEM", "1") != "0"
         # projection shortcuts on a parallel graph branch.  Off: measured on MI355X the
         # cross-queue dependencies of a forked HIP graph cost more than the overlap wins
         # (b8 0.590 vs 0.526 ms, b128 2.626 vs 2.614 ms); kept as an A/B switch.
@@ -238,10 +240,9 @@ class ResNet50(Model):
     # -- execution --
     def _forward_eager(self, x):
         torch = self._torch
-        x = x.contiguous(memory_format=torch.channels_last)
         if self.fused:
             return self._net.fc(self._features_fused(x)).float()
-        return self._net(x).float()
+        return self._net(x.contiguous(memory_format=torch.channels_last)).float()
 
     def _build_plan(self):
         """Flatten the folded network into plain tensors for the fused forward:
@@ -262,6 +263,13 @@ class ResNet50(Model):
         for blk in net.blocks:
             blocks.append((mat(blk.a), spatial(blk.b), mat(blk.c), mat(blk.down) if blk.down is not None else None))
         self._plan = (spatial(net.stem), blocks)
+        # the stem also as the packed matrix of the fused conv + bias + ReLU + max-pool kernel
+        from ..ops import conv
+
+        w = net.stem.conv
+        self._stem_packed = None
+        if (self.fused_stem and tuple(w.weight.shape) == (64, 3, 7, 7) and w.stride[0] == 2 and w.padding[0] == 3):
+            self._stem_packed = (conv.pack_stem_weight(w.weight), w.bias.contiguous())
 
     def _features_fused(self, x):
         """ResNet-50 trunk with every bias / residual / ReLU fused: 1x1
@@ -290,9 +298,14 @@ class ResNet50(Model):
             return conv.bias_act_(F.conv2d(t, w4, None, stride=stride, padding=pad), bias, None, True)
 
         stem, blocks = self._plan
-        # Cin = 3: library kernel; its bias + ReLU ride in the pooling pass
-        w4, bias, stride, pad = stem
-        y = conv.bias_relu_maxpool(F.conv2d(x, w4, None, stride=stride, padding=pad), bias)
+        if self._stem_packed is not None and x.is_contiguous() and x.shape[3] % 2 == 0:
+            # plain NCHW input (what clients send): the whole stem in one kernel
+            y = conv.stem_conv_pool(x, *self._stem_packed)
+        else:
+            # Cin = 3 on the library kernel; its bias + ReLU ride in the pooling pass
+            w4, bias, stride, pad = stem
+            x = x.contiguous(memory_format=torch.channels_last)
+            y = conv.bias_relu_maxpool(F.conv2d(x, w4, None, stride=stride, padding=pad), bias)
         main = torch.cuda.current_stream()
         side = self._side_stream if self.overlap_shortcut else None
         for a, mid, c, down in blocks:
@@ -316,8 +329,10 @@ class ResNet50(Model):
 
     def _forward_into(self, x, out):
         torch = self._torch
-        x = x.contiguous(memory_format=torch.channels_last)
-        feats = self._features_fused(x) if self.fused else self._net.features(x)
+        if self.fused:
+            feats = self._features_fused(x)  # takes the client's NCHW layout as it is
+        else:
+            feats = self._net.features(x.contiguous(memory_format=torch.channels_last))
         logits = self._net.fc(feats)
         out.copy_(logits)  # fp16 -> fp32 cast fused into the copy kernel
 

@@ -89,6 +89,8 @@ def install(lib):
     lib.tca_bias_act_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]
     lib.tca_bias_relu_maxpool_launch.restype = c_int
     lib.tca_bias_relu_maxpool_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.tca_stem_conv_pool_launch.restype = c_int
+    lib.tca_stem_conv_pool_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     install_rt(lib)
 
 

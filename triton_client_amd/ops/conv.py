@@ -182,3 +182,47 @@ def bias_relu_maxpool(x, bias, out=None):
     rc = lib().tca_bias_relu_maxpool_launch(x.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w, c, _stream())
     check(rc, "tca_bias_relu_maxpool_launch")
     return out
+
+
+def pack_stem_weight(weight):
+    """``[64, 3, 7, 7]`` convolution weight -> the ``[64, 192]`` fp16 matrix the
+    fused stem kernel reads: K ordered (c, kh, kw) with kw padded from 7 to 8 and
+    the total padded from 168 to 192, zeros in the padding.  The kw padding sits in
+    FRONT (slot kw + 1), which makes every 8-pixel run the kernel reads start at an
+    even input column."""
+    import torch
+
+    if tuple(weight.shape) != (64, 3, 7, 7):
+        raise ValueError("the fused stem expects a [64, 3, 7, 7] weight")
+    packed = torch.zeros(64, 192, dtype=torch.float16, device=weight.device)
+    padded = torch.zeros(64, 3, 7, 8, dtype=torch.float16, device=weight.device)
+    padded[:, :, :, 1:] = weight.to(torch.float16)
+    packed[:, :168] = padded.reshape(64, 168)
+    return packed.contiguous()
+
+
+def stem_conv_pool(x, packed_weight, bias, out=None):
+    """``max_pool2d(relu(conv2d(x, w, stride=2, padding=3) + bias), 3, 2, 1)`` for the
+    3-channel 7x7 network stem in one kernel.  ``x`` is a plain contiguous NCHW fp16
+    tensor (what clients send); the result is channels-last ``[N, 64, PH, PW]``."""
+    import torch
+
+    if x.dtype != torch.float16 or x.dim() != 4 or x.shape[1] != 3 or not x.is_contiguous():
+        raise ValueError("x must be a contiguous NCHW fp16 tensor with 3 channels")
+    if tuple(packed_weight.shape) != (64, 192) or packed_weight.dtype != torch.float16 or not packed_weight.is_contiguous():
+        raise ValueError("packed_weight must come from pack_stem_weight()")
+    if bias.numel() != 64 or bias.dtype != torch.float16 or not bias.is_contiguous():
+        raise ValueError("bias must be a contiguous fp16 vector of 64 elements")
+    n, _, h, w = x.shape
+    if w % 2:
+        raise ValueError("the fused stem reads rows as aligned dwords: the image width must be even")
+    oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((n, 64, ph, pw), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    elif tuple(out.shape) != (n, 64, ph, pw) or out.dtype != torch.float16 or not _is_nhwc(out):
+        raise ValueError("out must be a channels-last fp16 tensor of the pooled shape")
+    rc = lib().tca_stem_conv_pool_launch(x.data_ptr(), packed_weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w,
+                                         _stream())
+    check(rc, "tca_stem_conv_pool_launch")
+    return out
