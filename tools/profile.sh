@@ -58,12 +58,12 @@ PY
     sleep 2
 done
 timeout -k 10 200 python3 -m triton_client_amd.perf -m resnet50 -u 127.0.0.1:18001 -i grpc -b 8 --shared-memory hip \
-    --concurrency-range 16:16 -p 4000 -r 4 --json "$SUM/serving_c16_perf.json" > "$SUM/serving_c16_perf.txt" 2>&1
+    --concurrency-range 64:64 --native -p 3000 --stability-windows 2 --json "$SUM/serving_c64_perf.json" > "$SUM/serving_c64_perf.txt" 2>&1
 RC=$?
 kill $HOLD 2>/dev/null
 wait $SRV
 rm -f /tmp/srv_stdin
-tail -15 "$SUM/serving_c16_perf.txt"
+tail -15 "$SUM/serving_c64_perf.txt"
 [ $RC -eq 0 ] || exit 1
 python3 tools/summarize_stats.py "$(find "$OUT/server" -name '*kernel_stats.csv' | head -1)" "$SUM/serving_kernel_stats.csv" || exit 1
 rm -rf "$OUT/server"
