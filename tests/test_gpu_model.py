@@ -54,3 +54,48 @@ def test_graph_replay_equals_eager(model):
     model.stream.synchronize()
     # library kernels that split K accumulate with atomics, so two runs may differ by an fp16 ulp
     np.testing.assert_allclose(out.cpu().numpy(), eager.cpu().numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.gpu
+def test_gpu_ensemble_matches_client_side_preprocessing():
+    """Encoded images through ``preprocess_resnet50_ensemble`` (host decode, HIP
+    preprocessing, ResNet-50) give the logits of the same images preprocessed on
+    the client with the Pillow pipeline and sent to ``resnet50`` directly."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    import tritonclient.grpc as g
+    from triton_client_amd.ops.preprocess_ref import reference_preprocess
+    from triton_client_amd.server import Server
+
+    rng = np.random.default_rng(7)
+    pictures = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in ((300, 400), (224, 224), (97, 131))]
+    blobs = []
+    for pic in pictures:
+        buf = io.BytesIO()
+        Image.fromarray(pic).save(buf, format="PNG")  # lossless: both paths see the same pixels
+        blobs.append(buf.getvalue())
+    with Server(models=["resnet50", "preprocess_resnet50_ensemble"], gpu=0) as srv:
+        with g.InferenceServerClient(srv.grpc_url) as c:
+            assert c.is_model_ready("preprocess_resnet50_ensemble")
+            cfg = c.get_model_config("preprocess_resnet50_ensemble", as_json=True)["config"]
+            assert cfg["platform"] == "ensemble" and len(cfg["ensemble_scheduling"]["step"]) == 2
+            raw = np.array(blobs, dtype=np.object_).reshape(3, 1)
+            inp = g.InferInput("INPUT", [3, 1], "BYTES").set_data_from_numpy(raw)
+            got = c.infer("preprocess_resnet50_ensemble", [inp]).as_numpy("OUTPUT")
+            x = np.stack([reference_preprocess(p, 224, 224, 3, "NCHW", np.float16, "INCEPTION", "pil") for p in pictures])
+            direct = g.InferInput("input", [3, 3, 224, 224], "FP16").set_data_from_numpy(x)
+            ref = c.infer("resnet50", [direct]).as_numpy("output")
+            assert got.shape == ref.shape == (3, 1000)
+            np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2)
+            assert (got.argmax(axis=1) == ref.argmax(axis=1)).all()
+            # classification extension on the ensemble output
+            out = g.InferRequestedOutput("OUTPUT", class_count=2)
+            top = c.infer("preprocess_resnet50_ensemble", [inp], outputs=[out]).as_numpy("OUTPUT")
+            assert top.shape == (3, 2) and top[0, 0].decode().split(":")[1] == str(int(ref[0].argmax()))
+            # a broken file is a clean request error
+            bad = g.InferInput("INPUT", [1, 1], "BYTES").set_data_from_numpy(np.array([[b"not an image"]], dtype=np.object_))
+            with pytest.raises(Exception, match="unable to decode image"):
+                c.infer("preprocess_resnet50_ensemble", [bad])

@@ -154,6 +154,10 @@ class _GraphCache:
             self._items.popitem(last=False)
 
 
+# GPU models of this process by name: ensembles resolve their steps here
+_LOADED = {}
+
+
 @register
 class ResNet50(Model):
     name = "resnet50"
@@ -221,6 +225,7 @@ class ResNet50(Model):
         self._build_plan()
         self._stream = torch.cuda.Stream(device=self._device)
         self._side_stream = torch.cuda.Stream(device=self._device)
+        _LOADED[self.name] = self
         # immediate mode + the shipped tuned databases; TCA_MIOPEN_TUNE=1 runs
         # MIOpen's exhaustive search instead (tools/tune_miopen.py)
         torch.backends.cudnn.benchmark = os.environ.get("TCA_MIOPEN_TUNE", "0") == "1"
@@ -232,6 +237,8 @@ class ResNet50(Model):
         self._stream.synchronize()
 
     def unload(self):
+        if _LOADED.get(self.name) is self:
+            del _LOADED[self.name]
         self._graphs = _GraphCache()
         self._net = None
         if self._torch is not None:
@@ -393,3 +400,86 @@ class ResNet50Fp32In(ResNet50):
 
     name = "resnet50_fp32"
     inputs = [TensorSpec("input", "FP32", [3, 224, 224], format="FORMAT_NCHW")]
+
+
+@register
+class PreprocessResNet50Ensemble(Model):
+    """Encoded image files in, ImageNet logits out, everything after the decode on
+    the GPU: JPEG / PNG bytes (a BYTES tensor, one file per batch entry) are decoded
+    on the host, resized + INCEPTION-scaled + laid out as fp16 NCHW by the HIP
+    preprocessing kernel (bit-exact with the Pillow pipeline of ``image_client``)
+    straight into the classifier's input buffer, and classified by the loaded
+    ``resnet50`` instance.  This is the GPU counterpart of the reference's
+    ``preprocess_inception_ensemble`` (server-side DALI preprocessing,
+    ``src/python/examples/ensemble_image_client.py:60-110``)."""
+
+    name = "preprocess_resnet50_ensemble"
+    platform = "ensemble"
+    device = "gpu"
+    max_batch_size = 64
+    inputs = [TensorSpec("INPUT", "BYTES", [1])]
+    outputs = [TensorSpec("OUTPUT", "FP32", [1000], label_filename="labels.txt")]
+
+    def __init__(self):
+        super().__init__()
+        self.labels = [f"class_{i}" for i in range(1000)]
+        self._pre = None
+        self._torch = None
+        self._device = None
+        self._lock = threading.Lock()
+
+    def load(self, device_index=None):
+        import torch
+
+        from ..ops.preprocess import Preprocessor
+
+        self._torch = torch
+        index = device_index or 0
+        self._device = torch.device("cuda", index)
+        self._pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=index,
+                                 max_batch=self.max_batch_size)
+
+    def unload(self):
+        if self._pre is not None:
+            self._pre.close()
+            self._pre = None
+
+    def _classifier(self):
+        net = _LOADED.get("resnet50")
+        if net is None:
+            raise ModelError("ensemble step 'resnet50' is not loaded on this server")
+        return net
+
+    @property
+    def stream(self):
+        return self._classifier().stream
+
+    def execute(self, inputs, ctx):
+        import io
+
+        import numpy as np
+        from PIL import Image
+
+        torch = self._torch
+        net = self._classifier()
+        images = []
+        for blob in inputs["INPUT"].reshape(-1):
+            try:
+                img = Image.open(io.BytesIO(blob))
+                img.load()
+            except Exception as e:
+                raise ModelError(f"unable to decode image: {e}") from None
+            images.append(np.asarray(img.convert("RGB")))
+        with self._lock:  # one staging buffer set per preprocessor
+            x = torch.empty(len(images), 3, 224, 224, device=self._device, dtype=torch.float16)
+            self._pre(images, x)  # synchronises its own stream: x is complete on return
+            return {"OUTPUT": net.run(x)}
+
+    def config(self):
+        cfg = super().config()
+        cfg["ensemble_scheduling"] = {"step": [
+            {"model_name": "image_preprocess_hip", "model_version": -1, "input_map": {"INPUT": "INPUT"},
+             "output_map": {"OUTPUT": "preprocessed"}},
+            {"model_name": "resnet50", "model_version": -1, "input_map": {"input": "preprocessed"},
+             "output_map": {"output": "OUTPUT"}}]}
+        return cfg
