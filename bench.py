@@ -51,6 +51,9 @@ def parse_args():
                     help="native: C++ load generator (tca_loadgen) over the in-tree gRPC/HTTP client; "
                          "python: tritonclient-API threads in this process")
     ap.add_argument("--connections", type=int, default=4, help="gRPC channels the native load generator spreads over")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=os.environ.get("TCA_BENCH_DIST_BACKEND", "nccl"),
+                    help="nccl (= RCCL) for one rank per GPU; gloo only to rehearse several ranks on ONE GPU, "
+                         "which RCCL refuses")
     return ap.parse_args()
 
 
@@ -137,7 +140,7 @@ def measure_native(args, url, device, dist, label):
         pre.close()
     pcts = [result["p50_us"], result["p90_us"], result["p95_us"], result["p99_us"]]
     if dist is not None:
-        t = torch.tensor([elapsed] + pcts, device=f"cuda:{device}", dtype=torch.float64)
+        t = torch.tensor([elapsed] + pcts, device=args.reduce_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank bounds the job; percentiles: worst rank's
         elapsed, pcts = float(t[0].item()), [float(v) for v in t[1:].tolist()]
     world = dist.get_world_size() if dist is not None else 1
@@ -292,11 +295,11 @@ def measure(args, url, device, dist, label):
         for w in workers:
             w.close()
     if dist is not None:
-        t = torch.tensor([elapsed], device=f"cuda:{device}", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=args.reduce_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # latency samples of every rank -> rank 0 (fixed count per rank, gathered over RCCL)
-        mine = torch.zeros(args.steps * per_step, device=f"cuda:{device}", dtype=torch.float64)
+        mine = torch.zeros(args.steps * per_step, device=args.reduce_device, dtype=torch.float64)
         mine[: len(lat)] = torch.from_numpy(lat[: len(mine)]).to(mine.device)
         gathered = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(gathered, mine)
@@ -331,8 +334,12 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        if args.dist_backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_mod
+    args.reduce_device = f"cuda:{device}" if args.dist_backend == "nccl" else "cpu"
 
     from triton_client_amd.server import spawn_server
 

@@ -133,7 +133,7 @@ class Model:
                 for t in self.outputs
             ],
             "instance_group": [{"name": self.name + "_0", "kind": "KIND_GPU" if self.device == "gpu" else "KIND_CPU",
-                                "count": 1}],
+                                "count": int(getattr(self, "instance_count", 1))}],
             "model_transaction_policy": {"decoupled": self.decoupled},
             "parameters": {k: {"string_value": str(v)} for k, v in self.parameters.items()},
         }

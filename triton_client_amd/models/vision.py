@@ -190,6 +190,12 @@ class ResNet50(Model):
         # cross-queue dependencies of a forked HIP graph cost more than the overlap wins
         # (b8 0.590 vs 0.526 ms, b128 2.626 vs 2.614 ms); kept as an A/B switch.
         self.overlap_shortcut = os.environ.get("TCA_RESNET_OVERLAP", "0") != "0"
+        # Execution instances: each has its own HIP stream and its own captured graphs
+        # (with private activation pools), so the dynamic batcher keeps this many batches
+        # running side by side.  The tail of one batch's layers (fewer workgroups than the
+        # 256 CUs in the late stages) is filled by the other batch's kernels: two instances
+        # measured +13% inferences/sec over one at batch 128 on one MI355X.
+        self.instance_count = max(1, int(os.environ.get("TCA_RESNET_INSTANCES", "2")))
 
     # -- lifecycle --
     def load(self, device_index=None):
@@ -223,7 +229,8 @@ class ResNet50(Model):
             p.requires_grad_(False)
         self._net = net
         self._build_plan()
-        self._stream = torch.cuda.Stream(device=self._device)
+        self._streams = [torch.cuda.Stream(device=self._device) for _ in range(self.instance_count)]
+        self._stream = self._streams[0]
         self._side_stream = torch.cuda.Stream(device=self._device)
         _LOADED[self.name] = self
         # immediate mode + the shipped tuned databases; TCA_MIOPEN_TUNE=1 runs
@@ -343,42 +350,47 @@ class ResNet50(Model):
         logits = self._net.fc(feats)
         out.copy_(logits)  # fp16 -> fp32 cast fused into the copy kernel
 
-    def run(self, x, out=None):
+    def run(self, x, out=None, instance=0):
         """Forward ``x`` ([B,3,224,224] fp16 on this GPU).  When ``out`` (fp32
         [B,1000]) is given the logits are written there.  Work is enqueued on
-        the model stream; the caller synchronises via ``self.stream``."""
+        the stream of execution instance ``instance``; the caller synchronises
+        via ``self.stream_of(instance)`` (``self.stream`` for instance 0)."""
         torch = self._torch
         batch = x.shape[0]
+        stream = self._streams[instance]
         if out is None:
             out = torch.empty(batch, 1000, device=self._device, dtype=torch.float32)
         if not self.use_graphs:
-            with torch.no_grad(), torch.cuda.stream(self._stream):
+            with torch.no_grad(), torch.cuda.stream(stream):
                 self._forward_into(x, out)
             return out
-        key = (batch, x.data_ptr(), out.data_ptr())
+        key = (batch, x.data_ptr(), out.data_ptr(), instance)
         with self._lock:
             graph = self._graphs.get(key)
             if graph is None:
-                graph = self._capture(x, out)
+                graph = self._capture(x, out, stream)
                 self._graphs.put(key, graph)
-            with torch.cuda.stream(self._stream), _trace.range(f"resnet50 graph replay b={batch}"):
+            with torch.cuda.stream(stream), _trace.range(f"resnet50 graph replay b={batch}"):
                 graph[0].replay()
         return out
 
-    def _capture(self, x, out):
+    def _capture(self, x, out, stream):
         torch = self._torch
         with torch.no_grad():
-            with torch.cuda.stream(self._stream):
+            with torch.cuda.stream(stream):
                 self._forward_into(x, out)  # warm-up for this shape
-            self._stream.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._stream):
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()  # private memory pool: instances never share activations
+            with torch.cuda.graph(g, stream=stream):
                 self._forward_into(x, out)
         return (g, x, out)  # keep the tensors (hence the IPC mappings) alive
 
     @property
     def stream(self):
         return self._stream
+
+    def stream_of(self, instance):
+        return self._streams[instance]
 
     def execute(self, inputs, ctx):
         torch = self._torch
@@ -389,7 +401,7 @@ class ResNet50(Model):
             raise ModelError(f"unexpected shape for input 'input' for model 'resnet50'. Expected [-1,3,224,224], "
                              f"got {list(x.shape)}")
         out = inputs.get("__out__output")  # preallocated destination (e.g. a hipshm view)
-        result = self.run(x, out)
+        result = self.run(x, out, inputs.get("__instance__", 0))
         return {"output": result}
 
 

@@ -93,23 +93,36 @@ class DynamicBatcher:
         self.burst_window_s = float(getattr(self.model, "burst_window_us", 100)) / 1e6
         self._last_arrival_ns = 0
         self._last_done = (0, 1)  # (time, requests) of the batch that completed last
-        self._pinned_ring = []     # [pinned uint8 buffer, event of its last H2D copy, bytes used]
+        # Execution instances of the model (own HIP stream + own captured graphs each):
+        # batches are spread over them and run side by side on the GPU.
+        self.instances = int(getattr(self.model, "instance_count", 1)) if hasattr(self.model, "stream_of") else 1
+        self._busy = [0] * self.instances  # batches enqueued per instance (batcher adds, completers subtract)
+        self._busy_lock = threading.Lock()
+        # per instance: [ring of [pinned uint8 buffer, event of its last H2D copy, bytes used], next entry]
+        self._pinned = [[[], 0] for _ in range(self.instances)]
         self._pinned_bytes = 0
-        self._ring_next = 0
         self.q = queue.Queue()
-        self.completions = queue.Queue()
+        self.completions = [queue.Queue() for _ in range(self.instances)]
         self._held = None
         self._stop = False
         self._static = {}
-        # at most this many batches are enqueued on the GPU stream at once: while
-        # they run, arriving requests accumulate into ONE larger next batch
-        # instead of a train of small ones
-        self._inflight = threading.Semaphore(int(getattr(self.model, "max_inflight_batches", 2)))
+        # at most this many batches are enqueued on the GPU at once (two per instance: one
+        # running, one queued behind it): while they run, arriving requests accumulate
+        # into ONE larger next batch instead of a train of small ones
+        import os
+
+        cap = int(os.environ.get("TCA_MAX_INFLIGHT_BATCHES", 0)) or int(
+            getattr(self.model, "max_inflight_batches", 2 * self.instances))
+        self._inflight = threading.Semaphore(cap)
         self._prewarm()
         self._threads = [
-            threading.Thread(target=_profiled(self._batch_loop, "batcher"), name="tca-batcher", daemon=True),
-            threading.Thread(target=_profiled(self._complete_loop, "completer"), name="tca-completer", daemon=True),
-        ]
+            threading.Thread(target=_profiled(self._batch_loop, "batcher"), name="tca-batcher", daemon=True)]
+        for inst in range(self.instances):
+            # one completer per instance: a batch that finishes first on one stream is
+            # answered without waiting for an older batch on another
+            self._threads.append(threading.Thread(
+                target=_profiled(lambda inst=inst: self._complete_loop(inst), f"completer{inst}"),
+                name=f"tca-completer-{inst}", daemon=True))
         for t in self._threads:
             t.start()
 
@@ -127,16 +140,38 @@ class DynamicBatcher:
 
         np_dt = triton_to_np_dtype(spec.datatype)
         t_dt = torch.from_numpy(np.zeros(1, dtype=np_dt)).dtype
-        for b in sizes:
-            sbuf, obuf = self._static_buffers(b, spec.name, t_dt, tuple(spec.dims), model.outputs[0].name)
-            sbuf.zero_()
-            model.execute({spec.name: sbuf, "__out__" + model.outputs[0].name: obuf}, None)
-        model.stream.synchronize()
+        for inst in range(self.instances):
+            for b in sizes:
+                sbuf, obuf = self._static_buffers(inst, b, spec.name, t_dt, tuple(spec.dims), model.outputs[0].name)
+                sbuf.zero_()
+                model.execute({spec.name: sbuf, "__out__" + model.outputs[0].name: obuf, "__instance__": inst}, None)
+            self._stream_of(inst).synchronize()
+
+    def _stream_of(self, inst):
+        return self.model.stream_of(inst) if self.instances > 1 else self.model.stream
+
+    def _pick_instance(self, hint=None):
+        """Instance for the next batch: the one with the fewest batches enqueued.
+        ``hint`` (an address) pins single zero-copy requests to one instance, so
+        each client region is captured into one graph, not one per instance."""
+        with self._busy_lock:
+            if hint is not None:
+                inst = (hint >> 12) % self.instances
+            else:
+                inst = min(range(self.instances), key=self._busy.__getitem__)
+            self._busy[inst] += 1
+        return inst
+
+    def _instance_done(self, inst):
+        with self._busy_lock:
+            self._busy[inst] -= 1
+        self._inflight.release()
 
     def stop(self):
         self._stop = True
         self.q.put(None)
-        self.completions.put(None)
+        for c in self.completions:
+            c.put(None)
 
     # called on transport threads
     def submit(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version):
@@ -239,10 +274,10 @@ class DynamicBatcher:
                     it.error = err
                     it.finish()
 
-    def _static_buffers(self, total, in_name, in_dtype, in_tail, out_name):
+    def _static_buffers(self, inst, total, in_name, in_dtype, in_tail, out_name):
         import torch
 
-        key = total
+        key = (inst, total)
         bufs = self._static.get(key)
         if bufs is None:
             device = torch.device("cuda", self.lm.device_index or 0)
@@ -254,10 +289,22 @@ class DynamicBatcher:
         return bufs
 
     def _launch(self, group, total):
-        with _trace.range(f"batch {self.model.name} n={len(group)} b={total}"):
-            return self._launch_inner(group, total)
+        hint = None
+        if self.instances > 1 and len(group) == 1:
+            in_name = self.model.inputs[0].name
+            x = group[0].inputs.get(in_name)
+            if in_name in group[0].stable and hasattr(x, "data_ptr"):
+                hint = x.data_ptr()
+        inst = self._pick_instance(hint)
+        try:
+            with _trace.range(f"batch {self.model.name} n={len(group)} b={total} i={inst}"):
+                return self._launch_inner(group, total, inst)
+        except BaseException:
+            with self._busy_lock:
+                self._busy[inst] -= 1
+            raise
 
-    def _launch_inner(self, group, total):
+    def _launch_inner(self, group, total, inst):
         import torch
 
         model, core, lm = self.model, self.core, self.lm
@@ -265,7 +312,7 @@ class DynamicBatcher:
         in_name = model.inputs[0].name
         out_name = model.outputs[0].name
         t_exec = time.perf_counter_ns()
-        stream = model.stream
+        stream = self._stream_of(inst)
         pending = []  # (item, dev_inputs or None, host copies)
         if len(group) == 1:
             it = group[0]
@@ -276,11 +323,12 @@ class DynamicBatcher:
                 # graph reads (stable address), no intermediate device tensor
                 dev_inputs = core._to_device(lm, {k: v for k, v in it.inputs.items() if k != in_name}, it.stable)
                 x_dtype = torch.from_numpy(host_x[:0].copy()).dtype
-                sbuf, _ = self._static_buffers(it.batch, in_name, x_dtype, tuple(host_x.shape[1:]), out_name)
-                self._stage_host(host_x, sbuf, stream)
+                sbuf, _ = self._static_buffers(inst, it.batch, in_name, x_dtype, tuple(host_x.shape[1:]), out_name)
+                self._stage_many([(host_x, sbuf)], stream, inst)
                 dev_inputs[in_name] = sbuf
             else:
                 dev_inputs = core._to_device(lm, it.inputs, it.stable)
+            dev_inputs["__instance__"] = inst
             for ro in it.requested:
                 dest = core._output_destination(lm, ro, out_specs[ro.name], it.batch)
                 if dest is not None:
@@ -289,12 +337,12 @@ class DynamicBatcher:
             if not staged and in_name not in it.stable:
                 # device tensor that is not in a registered region: copy into the static
                 # buffer so the captured graph sees a stable address
-                sbuf, _ = self._static_buffers(it.batch, in_name, x.dtype, tuple(x.shape[1:]), out_name)
+                sbuf, _ = self._static_buffers(inst, it.batch, in_name, x.dtype, tuple(x.shape[1:]), out_name)
                 with torch.cuda.stream(stream):
                     sbuf.copy_(x, non_blocking=True)
                 dev_inputs[in_name] = sbuf
             if ("__out__" + out_name) not in dev_inputs:
-                _, obuf = self._static_buffers(it.batch, in_name, dev_inputs[in_name].dtype,
+                _, obuf = self._static_buffers(inst, it.batch, in_name, dev_inputs[in_name].dtype,
                                                tuple(dev_inputs[in_name].shape[1:]), out_name)
                 dev_inputs["__out__" + out_name] = obuf
                 result = model.execute(dev_inputs, it.ctx)
@@ -310,7 +358,7 @@ class DynamicBatcher:
             else:
                 in_dtype = first.dtype
             tail = tuple(first.shape[1:])
-            sbuf, obuf = self._static_buffers(total, in_name, in_dtype, tail, out_name)
+            sbuf, obuf = self._static_buffers(inst, total, in_name, in_dtype, tail, out_name)
             from ..ops.copy import batched_copy
 
             # gather: device-resident inputs (hipshm) go through ONE batched copy
@@ -329,9 +377,9 @@ class DynamicBatcher:
                     else:
                         sbuf[row: row + it.batch].copy_(x, non_blocking=True)
                     row += it.batch
-            self._stage_many(host_pairs, stream)
+            self._stage_many(host_pairs, stream, inst)
             batched_copy(gather, stream)
-            merged = {in_name: sbuf, "__out__" + out_name: obuf}
+            merged = {in_name: sbuf, "__out__" + out_name: obuf, "__instance__": inst}
             out = model.execute(merged, group[0].ctx)[out_name]
             # scatter the output rows into the requests' shm destinations, again in one launch
             row = 0
@@ -361,24 +409,23 @@ class DynamicBatcher:
             batched_copy(scatter, stream)
         event = torch.cuda.Event()
         event.record(stream)
-        self.completions.put((event, pending, total, t_exec, time.perf_counter_ns()))
+        self.completions[inst].put((event, pending, total, t_exec, time.perf_counter_ns()))
 
-    def _stage_host(self, arr, dst, stream):
-        self._stage_many([(arr, dst)], stream)
-
-    def _stage_many(self, pairs, stream):
+    def _stage_many(self, pairs, stream, inst):
         """Host arrays -> device tensors through a ring of pinned buffers: one CPU
         memcpy per array into page-locked memory, then asynchronous H2D copies on the
         model stream.  A copy from pageable memory would be staged by the
         runtime in small synchronous chunks on this thread instead.  A ring entry is
-        reused only after the H2D copies that read it have finished."""
+        reused only after the H2D copies that read it have finished; every execution
+        instance has its own ring because those copies run on its stream."""
         import torch
 
         if not pairs:
             return
         srcs = [torch.from_numpy(np.ascontiguousarray(arr)) for arr, _ in pairs]
         sizes = [t.numel() * t.element_size() for t in srcs]
-        ring = self._pinned_ring
+        state = self._pinned[inst]
+        ring = state[0]
         need = max(sizes)
         if not ring or need > ring[0][0].numel():
             # (re)allocate.  Deliberately small - a few entries of one request each: the ring
@@ -389,18 +436,18 @@ class DynamicBatcher:
             per_entry = max(need, self._pinned_bytes)
             self._pinned_bytes = per_entry
             ring[:] = [[torch.empty(per_entry, dtype=torch.uint8, pin_memory=True), None, 0] for _ in range(4)]
-            self._ring_next = 0
+            state[1] = 0
         # One tensor at a time: reserve a ring slot (waiting for the H2D copy that last read
         # it), memcpy, issue the H2D copy, mark the slot.  Serial memcpys on purpose (a thread
         # pool here was measured to halve the wire throughput: the extra threads fight the
         # transport callbacks for the GIL); the DMA of one tensor overlaps the memcpy of the next.
         with torch.cuda.stream(stream):
             for (_, dst), src, nbytes in zip(pairs, srcs, sizes):
-                entry = ring[self._ring_next]
+                entry = ring[state[1]]
                 if entry[1] is None or entry[2] + nbytes > entry[0].numel():
                     if entry[1] is not None:  # full: move on and wait for the next entry's last reader
-                        self._ring_next = (self._ring_next + 1) % len(ring)
-                        entry = ring[self._ring_next]
+                        state[1] = (state[1] + 1) % len(ring)
+                        entry = ring[state[1]]
                         if entry[1] is not None:
                             entry[1].synchronize()
                     entry[1] = torch.cuda.Event()
@@ -436,17 +483,17 @@ class DynamicBatcher:
         return out
 
     # ---------------------------------------------------------- completion
-    def _complete_loop(self):
+    def _complete_loop(self, inst):
         import torch
 
         torch.cuda.set_device(self.lm.device_index or 0)
         while True:
-            entry = self.completions.get()
+            entry = self.completions[inst].get()
             if entry is None:
                 break
             event, pending, total, t_exec, t_enq = entry
             event.synchronize()
-            self._inflight.release()
+            self._instance_done(inst)
             t_done = time.perf_counter_ns()
             self._last_done = (t_done, len(pending))  # closed-loop clients send this many again shortly
             out_specs = {t.name: t for t in self.model.outputs}
