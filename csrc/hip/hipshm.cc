@@ -26,6 +26,7 @@
 
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -77,10 +78,21 @@ struct DeviceCtx {
   std::mutex mu;
 };
 
-constexpr size_t kStageBytes = 8u << 20;  // per half of the ring
+constexpr size_t kStageBytes = 8u << 20;       // per half of the ring, first engine of a device (bulk copies)
+constexpr size_t kSmallStageBytes = 1u << 20;  // the other engines: small copies of concurrent requests
+constexpr int kEnginesPerDevice = 4;
+constexpr size_t kSpinBytes = 256u << 10;      // copies up to this size poll for completion instead of sleeping
+
+// Copy engines of one device.  A serving process moves many small tensors for
+// concurrent requests (BYTES tensors in device regions are read and written through
+// the host): one engine would serialise them behind one mutex and one stream.
+struct DevicePool {
+  DeviceCtx* engine[kEnginesPerDevice] = {nullptr};
+  std::atomic<unsigned> next{0};
+};
 
 std::mutex g_ctx_mu;
-std::unordered_map<int, DeviceCtx*> g_ctx;
+std::unordered_map<int, DevicePool*> g_ctx;
 
 class DeviceGuard {
  public:
@@ -98,24 +110,67 @@ class DeviceGuard {
   bool ok_ = false;
 };
 
-int GetCtx(int device, DeviceCtx** out) {
-  std::lock_guard<std::mutex> lk(g_ctx_mu);
-  auto it = g_ctx.find(device);
-  if (it != g_ctx.end()) {
-    *out = it->second;
-    return 0;
-  }
+int NewEngine(int device, size_t stage_bytes, DeviceCtx** out) {
   DeviceGuard guard(device);
   if (!guard.ok()) return FailMsg("hipSetDevice(" + std::to_string(device) + ") failed");
   auto* ctx = new DeviceCtx();
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
   for (int i = 0; i < 2; ++i) {
-    HIP_TRY(hipHostMalloc(&ctx->pinned[i], kStageBytes, hipHostMallocDefault), "hipHostMalloc(staging)");
+    HIP_TRY(hipHostMalloc(&ctx->pinned[i], stage_bytes, hipHostMallocDefault), "hipHostMalloc(staging)");
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming), "hipEventCreate");
   }
-  ctx->pinned_size = kStageBytes;
-  g_ctx[device] = ctx;
+  ctx->pinned_size = stage_bytes;
   *out = ctx;
+  return 0;
+}
+
+// A locked copy engine of `device`: the first idle one (engines are created on demand,
+// so a single-threaded client only ever owns one), else the next in turn once it frees up.
+class EngineLease {
+ public:
+  int Acquire(int device) {
+    DevicePool* pool = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_ctx_mu);
+      auto it = g_ctx.find(device);
+      if (it == g_ctx.end()) it = g_ctx.emplace(device, new DevicePool()).first;
+      pool = it->second;
+      for (int i = 0; i < kEnginesPerDevice; ++i) {
+        if (pool->engine[i] == nullptr) {
+          int rc = NewEngine(device, i == 0 ? kStageBytes : kSmallStageBytes, &pool->engine[i]);
+          if (rc) return rc;
+        }
+        if (pool->engine[i]->mu.try_lock()) {
+          ctx_ = pool->engine[i];
+          return 0;
+        }
+      }
+    }
+    ctx_ = pool->engine[pool->next.fetch_add(1) % kEnginesPerDevice];
+    ctx_->mu.lock();
+    return 0;
+  }
+  ~EngineLease() {
+    if (ctx_) ctx_->mu.unlock();
+  }
+  DeviceCtx* get() const { return ctx_; }
+
+ private:
+  DeviceCtx* ctx_ = nullptr;
+};
+
+// Waits for `ev`.  A small copy finishes within microseconds: polling sees it at once,
+// where a blocking wait pays the wake-up of a sleeping thread (tens of microseconds).
+int WaitEvent(hipEvent_t ev, bool small) {
+  if (small) {
+    const auto give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+    do {
+      const hipError_t e = hipEventQuery(ev);
+      if (e == hipSuccess) return 0;
+      if (e != hipErrorNotReady) return Fail("hipEventQuery", e);
+    } while (std::chrono::steady_clock::now() < give_up);
+  }
+  HIP_TRY(hipEventSynchronize(ev), "hipEventSynchronize");
   return 0;
 }
 
@@ -164,6 +219,7 @@ int StagedH2D(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
   char* d = static_cast<char*>(dst);
   int slot = 0;
   bool used[2] = {false, false};
+  const bool small = n <= kSpinBytes;
   while (n) {
     size_t chunk = n < ctx->pinned_size ? n : ctx->pinned_size;
     if (used[slot]) HIP_TRY(hipEventSynchronize(ctx->ev[slot]), "hipEventSynchronize");
@@ -176,8 +232,7 @@ int StagedH2D(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
     n -= chunk;
     slot ^= 1;
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-  return 0;
+  return WaitEvent(ctx->ev[slot ^ 1], small);  // the event of the last chunk: the stream is in order
 }
 
 int StagedD2H(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
@@ -187,6 +242,7 @@ int StagedD2H(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
   size_t issued = 0, drained = 0;
   size_t sizes[2] = {0, 0};
   int head = 0, tail = 0, inflight = 0;
+  const bool small = n <= kSpinBytes;
   while (drained < n) {
     while (inflight < 2 && issued < n) {
       size_t chunk = (n - issued) < ctx->pinned_size ? (n - issued) : ctx->pinned_size;
@@ -198,7 +254,7 @@ int StagedD2H(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
       head ^= 1;
       ++inflight;
     }
-    HIP_TRY(hipEventSynchronize(ctx->ev[tail]), "hipEventSynchronize");
+    if (int rc = WaitEvent(ctx->ev[tail], small)) return rc;
     std::memcpy(d + drained, ctx->pinned[tail], sizes[tail]);
     drained += sizes[tail];
     tail ^= 1;
@@ -294,12 +350,11 @@ int tca_hipshm_write(void* handle, uint64_t offset, const void* src, uint64_t n)
   if (rc) return rc;
   if (n == 0) return 0;
   if (r->fake) { std::memcpy(static_cast<char*>(r->ptr) + offset, src, n); return 0; }
-  DeviceCtx* ctx = nullptr;
-  rc = GetCtx(r->device, &ctx);
-  if (rc) return rc;
   DeviceGuard guard(r->device);
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  return StagedH2D(ctx, static_cast<char*>(r->ptr) + offset, src, n);
+  EngineLease lease;
+  rc = lease.Acquire(r->device);
+  if (rc) return rc;
+  return StagedH2D(lease.get(), static_cast<char*>(r->ptr) + offset, src, n);
 }
 
 // Region -> host; only the requested range moves.
@@ -310,12 +365,101 @@ int tca_hipshm_read(void* handle, uint64_t offset, void* dst, uint64_t n) {
   if (rc) return rc;
   if (n == 0) return 0;
   if (r->fake) { std::memcpy(dst, static_cast<char*>(r->ptr) + offset, n); return 0; }
-  DeviceCtx* ctx = nullptr;
-  rc = GetCtx(r->device, &ctx);
-  if (rc) return rc;
   DeviceGuard guard(r->device);
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  return StagedD2H(ctx, dst, static_cast<char*>(r->ptr) + offset, n);
+  EngineLease lease;
+  rc = lease.Acquire(r->device);
+  if (rc) return rc;
+  return StagedD2H(lease.get(), dst, static_cast<char*>(r->ptr) + offset, n);
+}
+
+// Several small region -> host reads (the input tensors of one request) as ONE trip:
+// every copy is enqueued, then one wait.  Falls back to one read at a time when the
+// ranges are on different devices, host-backed, or larger than a staging buffer.
+int tca_hipshm_read_many(int count, void* const* handles, const uint64_t* offsets, void* const* dsts,
+                         const uint64_t* sizes) {
+  if (count <= 0) return 0;
+  uint64_t total = 0;
+  bool batched = true;
+  for (int i = 0; i < count; ++i) {
+    auto* r = static_cast<Region*>(handles[i]);
+    if (!r) return FailMsg("null region");
+    int rc = CheckRange(r, offsets[i], sizes[i]);
+    if (rc) return rc;
+    if (r->fake || r->device != static_cast<Region*>(handles[0])->device) batched = false;
+    total += (sizes[i] + 63) & ~63ull;
+  }
+  if (!batched || total > kSmallStageBytes) {
+    for (int i = 0; i < count; ++i) {
+      int rc = tca_hipshm_read(handles[i], offsets[i], dsts[i], sizes[i]);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  const int device = static_cast<Region*>(handles[0])->device;
+  DeviceGuard guard(device);
+  EngineLease lease;
+  int rc = lease.Acquire(device);
+  if (rc) return rc;
+  DeviceCtx* ctx = lease.get();
+  char* stage = static_cast<char*>(ctx->pinned[0]);
+  uint64_t cursor = 0;
+  for (int i = 0; i < count; ++i) {
+    if (sizes[i] == 0) continue;
+    auto* r = static_cast<Region*>(handles[i]);
+    HIP_TRY(hipMemcpyAsync(stage + cursor, static_cast<char*>(r->ptr) + offsets[i], sizes[i], hipMemcpyDeviceToHost,
+                           ctx->stream), "hipMemcpyAsync(D2H)");
+    cursor += (sizes[i] + 63) & ~63ull;
+  }
+  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
+  rc = WaitEvent(ctx->ev[0], total <= kSpinBytes);
+  if (rc) return rc;
+  cursor = 0;
+  for (int i = 0; i < count; ++i) {
+    std::memcpy(dsts[i], stage + cursor, sizes[i]);
+    cursor += (sizes[i] + 63) & ~63ull;
+  }
+  return 0;
+}
+
+// The counterpart for the output tensors of one request: host -> regions, one wait.
+int tca_hipshm_write_many(int count, void* const* handles, const uint64_t* offsets, const void* const* srcs,
+                          const uint64_t* sizes) {
+  if (count <= 0) return 0;
+  uint64_t total = 0;
+  bool batched = true;
+  for (int i = 0; i < count; ++i) {
+    auto* r = static_cast<Region*>(handles[i]);
+    if (!r) return FailMsg("null region");
+    int rc = CheckRange(r, offsets[i], sizes[i]);
+    if (rc) return rc;
+    if (r->fake || r->device != static_cast<Region*>(handles[0])->device) batched = false;
+    total += (sizes[i] + 63) & ~63ull;
+  }
+  if (!batched || total > kSmallStageBytes) {
+    for (int i = 0; i < count; ++i) {
+      int rc = tca_hipshm_write(handles[i], offsets[i], srcs[i], sizes[i]);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  const int device = static_cast<Region*>(handles[0])->device;
+  DeviceGuard guard(device);
+  EngineLease lease;
+  int rc = lease.Acquire(device);
+  if (rc) return rc;
+  DeviceCtx* ctx = lease.get();
+  char* stage = static_cast<char*>(ctx->pinned[0]);
+  uint64_t cursor = 0;
+  for (int i = 0; i < count; ++i) {
+    if (sizes[i] == 0) continue;
+    auto* r = static_cast<Region*>(handles[i]);
+    std::memcpy(stage + cursor, srcs[i], sizes[i]);
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(r->ptr) + offsets[i], stage + cursor, sizes[i], hipMemcpyHostToDevice,
+                           ctx->stream), "hipMemcpyAsync(H2D)");
+    cursor += (sizes[i] + 63) & ~63ull;
+  }
+  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
+  return WaitEvent(ctx->ev[0], total <= kSpinBytes);
 }
 
 // Any address the runtime can classify (device, pinned host, peer device) ->
@@ -328,11 +472,11 @@ int tca_hipshm_copy_from(void* handle, uint64_t offset, const void* src, uint64_
   if (n == 0) return 0;
   if (r->fake) { std::memcpy(static_cast<char*>(r->ptr) + offset, src, n); return 0; }
   if (src_device < 0) return tca_hipshm_write(handle, offset, src, n);
-  DeviceCtx* ctx = nullptr;
-  rc = GetCtx(r->device, &ctx);
-  if (rc) return rc;
   DeviceGuard guard(r->device);
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  EngineLease lease;
+  rc = lease.Acquire(r->device);
+  if (rc) return rc;
+  DeviceCtx* ctx = lease.get();
   if (src_device != r->device) {
     int can = 0;
     (void)hipDeviceCanAccessPeer(&can, r->device, src_device);

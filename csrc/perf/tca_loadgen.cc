@@ -133,10 +133,20 @@ int main(int argc, char** argv) {
       if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
       const int64_t count = tca::ElementCount(dims);
       size_t bytes = static_cast<size_t>(count) * tca::DataTypeByteSize(parts[1]);
-      if (parts[1] == "BYTES") bytes = static_cast<size_t>(count) * 5;  // "0" per element
-      slot->storage.emplace_back(bytes, 0);
-      if (parts[1] == "BYTES")
-        for (int64_t k = 0; k < count; ++k) { slot->storage.back()[k * 5] = 1; slot->storage.back()[k * 5 + 4] = '0'; }
+      if (parts[1] == "BYTES") {
+        // decimal strings "0".."99" (models such as simple_string parse them), <u32 length><bytes> each
+        std::vector<uint8_t> packed;
+        for (int64_t k = 0; k < count; ++k) {
+          const std::string text = std::to_string((k * 7 + s) % 100);
+          const uint32_t len = static_cast<uint32_t>(text.size());
+          for (int b = 0; b < 4; ++b) packed.push_back(static_cast<uint8_t>(len >> (8 * b)));
+          packed.insert(packed.end(), text.begin(), text.end());
+        }
+        bytes = packed.size();
+        slot->storage.push_back(std::move(packed));
+      } else {
+        slot->storage.emplace_back(bytes, 0);
+      }
       in->AppendRaw(slot->storage.back().data(), bytes);
       slot->inputs.emplace_back(in);
       slot->in_ptrs.push_back(in);

@@ -91,6 +91,20 @@ def test_native_generator_mode(two_servers, proto, shm):
         assert not c.get_system_shared_memory_status(as_json=True).get("regions")
 
 
+@pytest.mark.parametrize("proto,shm", [("grpc", "none"), ("grpc", "system"), ("http", "system")])
+def test_native_generator_drives_bytes_tensors(two_servers, proto, shm):
+    """BYTES inputs (length-prefixed decimal strings the model parses) on the wire and
+    serialized into shared-memory regions, with the BYTES outputs placed in regions."""
+    from triton_client_amd import _build
+
+    _build.build_cpp()
+    a, _ = two_servers
+    url = a.grpc_url if proto == "grpc" else a.http_url
+    rows = _run(["-m", "simple_string", "-u", url, "-i", proto, "--shared-memory", shm, "--native",
+                 "--concurrency-range", "3", "-p", "200", "--stability-windows", "2", "--warmup-ms", "100"])
+    assert rows[0]["errors"] == 0 and rows[0]["requests"] > 20 and rows[0]["infer_per_sec"] > 50
+
+
 def test_native_mode_rejects_open_loop(two_servers):
     a, _ = two_servers
     with pytest.raises(SystemExit):

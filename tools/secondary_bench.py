@@ -44,9 +44,9 @@ def main():
         emit("simple_grpc_wire", concurrency=16, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
              p99_us=rows[0]["p99_us"])
         shm = "hip" if args.gpu is not None else "system"
-        rows = perf(["-m", "simple_string", "-u", srv.grpc_url, "-i", "grpc", "--shared-memory", shm,
-                     "--concurrency-range", "8", "--worker-processes", "4", "-r", "6"] + common)
-        emit(f"string_grpc_{shm}shm", concurrency=8, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
+        rows = perf(["-m", "simple_string", "-u", srv.grpc_url, "-i", "grpc", "--shared-memory", shm, "--native",
+                     "--concurrency-range", "16"] + common)
+        emit(f"string_grpc_{shm}shm", concurrency=16, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
              p99_us=rows[0]["p99_us"])
 
         import tritonclient.grpc as g

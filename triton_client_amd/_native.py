@@ -114,6 +114,28 @@ def hip():
     return _hip
 
 
+_hip_held = None
+
+
+def hip_gil_held():
+    """The same library through ``ctypes.PyDLL``: calls keep the GIL.  For native calls
+    of a few microseconds (small shared-memory copies) in a process with many busy
+    threads, where giving the interpreter away and queueing to get it back costs far
+    more than the call itself."""
+    global _hip_held
+    if _hip_held is not None:
+        return _hip_held
+    hip()
+    with _lock:
+        if _hip_held is None:
+            lib = ctypes.PyDLL(_ensure("hip", "libtca_hip.so"))
+            from .ops import _bind
+
+            _bind.install(lib)
+            _hip_held = lib
+    return _hip_held
+
+
 def pyext():
     """The ``_tca_pyext`` CPython extension (built on demand): BYTES codec and
     the native gRPC serving front."""

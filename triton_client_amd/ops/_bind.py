@@ -46,6 +46,9 @@ def install(lib):
     lib.tca_hipshm_write.argtypes = [c_void_p, c_uint64, c_void_p, c_uint64]
     lib.tca_hipshm_read.restype = c_int
     lib.tca_hipshm_read.argtypes = [c_void_p, c_uint64, c_void_p, c_uint64]
+    for fn in (lib.tca_hipshm_read_many, lib.tca_hipshm_write_many):
+        fn.restype = c_int
+        fn.argtypes = [c_int, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_void_p), POINTER(c_uint64)]
     lib.tca_hipshm_copy_from.restype = c_int
     lib.tca_hipshm_copy_from.argtypes = [c_void_p, c_uint64, c_void_p, c_uint64, c_int]
     lib.tca_hipshm_copy_from_async.restype = c_int

@@ -610,6 +610,7 @@ class InferenceCore:
         batch = 0
         gpu = model.device == "gpu"
         stable = set()
+        deferred = []
         for t in req.inputs:
             spec = specs.get(t.name)
             if spec is None:
@@ -636,8 +637,8 @@ class InferenceCore:
                 raise ServerError(
                     f"unexpected shape for input '{t.name}' for model '{model.name}'. Expected {dims}, got {shape}")
             if t.shm is not None:
-                arr = self._read_shm(t, shape, model, gpu)
-                if gpu and not isinstance(arr, np.ndarray):
+                arr = self._read_shm(t, shape, model, gpu, deferred)
+                if gpu and not isinstance(arr, np.ndarray) and arr is not None:
                     stable.add(t.name)
             elif t.data is not None:
                 arr = t.data
@@ -648,6 +649,14 @@ class InferenceCore:
             else:
                 raise ServerError(f"input '{t.name}' for model '{model.name}' has no data")
             inputs[t.name] = arr
+        if deferred:
+            # tensors that go through the host although they sit in device regions (BYTES,
+            # inputs of CPU models): all ranges of the request move in one native call
+            from ..utils import hip_shared_memory as hipshm
+
+            hosts = hipshm.read_mappings([(mapping, ref.offset, ref.byte_size) for _, _, mapping, ref in deferred])
+            for (t, shape, _, _), host in zip(deferred, hosts):
+                inputs[t.name] = _decode_wire(t.datatype, shape, host, t.name, model.name)
         missing = [n for n, s in specs.items() if n not in seen and not s.optional]
         if missing:
             raise ServerError(
@@ -656,7 +665,7 @@ class InferenceCore:
                 "Please provide all required input(s).")
         return inputs, batch, stable
 
-    def _read_shm(self, t: InputTensor, shape, model, gpu):
+    def _read_shm(self, t: InputTensor, shape, model, gpu, deferred):
         ref = t.shm
         view = self.sysshm.view(ref)
         if view is not None:
@@ -671,8 +680,8 @@ class InferenceCore:
             raise ServerError(f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
         if gpu and t.datatype != "BYTES":
             return self.devshm.tensor_view(ref.region, mapping, t.datatype, shape, ref.offset)
-        host = hipshm.read_mapping(mapping, ref.offset, ref.byte_size)
-        return _decode_wire(t.datatype, shape, host, t.name, model.name)
+        deferred.append((t, shape, mapping, ref))  # read together with the request's other ranges
+        return None
 
     def _output_destination(self, lm, ro: RequestedOutput, spec, batch):
         """For GPU models: a torch view of the device shm destination, if any."""
@@ -866,6 +875,7 @@ class InferenceCore:
     def _build_response(self, lm, req, result, requested, out_specs, version, batch, dev_inputs=None):
         model = lm.model
         response = InferResponse(model_name=req.model_name, model_version=version, id=req.id)
+        device_writes = []  # (mapping, offset, blob) of outputs bound for device regions: one native call
         for ro in requested:
             spec = out_specs[ro.name]
             if ro.name not in result:
@@ -888,10 +898,14 @@ class InferenceCore:
                     value = value.astype(want)
             shape = list(value.shape)
             if ro.shm is not None:
-                self._write_shm(ro, datatype, value)
+                self._write_shm(ro, datatype, value, device_writes)
                 response.outputs.append(OutputTensor(ro.name, datatype, shape, None, ro.shm))
             else:
                 response.outputs.append(OutputTensor(ro.name, datatype, shape, value, None, ro.binary))
+        if device_writes:
+            from ..utils import hip_shared_memory as hipshm
+
+            hipshm.write_mappings(device_writes)
         return response
 
     def _to_host(self, value):
@@ -909,7 +923,7 @@ class InferenceCore:
             return PackedBytes(blob, shape)
         return format_classification(value, labels, k)
 
-    def _write_shm(self, ro: RequestedOutput, datatype, value):
+    def _write_shm(self, ro: RequestedOutput, datatype, value, device_writes=None):
         ref = ro.shm
         blob = encode_wire(datatype, value)
         if len(blob) > ref.byte_size:
@@ -927,7 +941,10 @@ class InferenceCore:
 
         if ref.offset + len(blob) > entry[1]:
             raise ServerError(f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
-        hipshm.write_mapping(entry[2], ref.offset, blob)
+        if device_writes is not None:
+            device_writes.append((entry[2], ref.offset, blob))
+        else:
+            hipshm.write_mapping(entry[2], ref.offset, blob)
 
     def shutdown(self):
         with self._lock:
