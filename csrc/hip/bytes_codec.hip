@@ -16,6 +16,8 @@
 //          (coalesced 16-byte loads by all 256 threads) and a single lane walks
 //          the chain out of LDS; the 100-cycle LDS hop replaces a ~2 us HBM hop
 //          per element.  `status` reports count and the first malformed offset.
+//          Streams of more than a few chunks use the chunk-parallel form (see
+//          "parallel index" below): serial only across 4 KiB chunks.
 //  gather  wire + index -> fixed pitch rows (zero padded) for device-side
 //          consumers such as a tokenizer front end.
 #include <hip/hip_runtime.h>
@@ -160,6 +162,158 @@ __global__ __launch_bounds__(kThreads) void BytesIndexKernel(const uint8_t* __re
   }
 }
 
+// ---------------------------------------------------------- parallel index
+// The prefix chain is serial only ACROSS chunks.  Inside a chunk of kMapChunk bytes the
+// question "entering at byte e, where does the chain leave the chunk and how many
+// elements does it pass" is answered for EVERY e at once by pointer jumping in LDS
+// (each position first points at the header that would follow it; log2 rounds of
+// "jump to my successor's successor" collapse every path).  A single lane then crosses
+// the stream with ONE table lookup per chunk instead of one dependent load per
+// element, and finally every chunk that the chain entered emits its elements on its own.
+//
+//   map    (one workgroup per chunk)  table[c][e] = packed {exit, count, flag}
+//   chain  (one lane)                 entry byte + first element number of every chunk
+//   emit   (one workgroup per chunk)  offsets[] / lens[] of the chunk's elements
+constexpr uint32_t kMapChunk = 4096;
+constexpr uint32_t kMapExited = 0x1FFF;          // 13-bit "next" field: the path has left the chunk
+constexpr uint32_t kFlagOk = 0, kFlagEnd = 1, kFlagBad = 2;
+constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
+
+// 64-bit node: [12:0] next header in the chunk (or kMapExited), [23:13] headers passed,
+// [25:24] flag, [63:26] once exited: bytes past the chunk end where the chain continues
+// (END / BAD: the position inside the chunk where it stopped).
+__device__ inline uint64_t MapNode(uint32_t next, uint32_t count, uint32_t flag, uint64_t payload) {
+  return static_cast<uint64_t>(next) | (static_cast<uint64_t>(count) << 13) | (static_cast<uint64_t>(flag) << 24) |
+         (payload << 26);
+}
+__device__ inline uint32_t NodeNext(uint64_t t) { return static_cast<uint32_t>(t) & 0x1FFFu; }
+__device__ inline uint32_t NodeCount(uint64_t t) { return (static_cast<uint32_t>(t) >> 13) & 0x7FFu; }
+__device__ inline uint32_t NodeFlag(uint64_t t) { return (static_cast<uint32_t>(t) >> 24) & 3u; }
+__device__ inline uint64_t NodePayload(uint64_t t) { return t >> 26; }
+
+// Stages bytes [base, base + kMapChunk + 8) of the stream (zero past its end) into LDS.
+__device__ inline void StageChunk(const uint8_t* __restrict__ s, uint64_t size, uint64_t base, uint8_t* lds) {
+  const uint64_t avail = size - base < kMapChunk + 8 ? size - base : kMapChunk + 8;
+  const bool aligned = (reinterpret_cast<uintptr_t>(s + base) & 15) == 0;
+  for (uint32_t off = threadIdx.x * 16; off < kMapChunk + 16; off += kThreads * 16) {
+    if (aligned && off + 16 <= avail) {
+      *reinterpret_cast<uint4*>(lds + off) = *reinterpret_cast<const uint4*>(s + base + off);
+    } else {
+      for (uint32_t j = off; j < off + 16; ++j) lds[j] = j < avail ? s[base + j] : 0;
+    }
+  }
+}
+
+__device__ inline uint32_t LdsPrefix(const uint8_t* lds, uint32_t rel) {
+  const uint32_t* words = reinterpret_cast<const uint32_t*>(lds + (rel & ~3u));
+  const uint32_t lo = words[0], hi = words[1];
+  const uint32_t shift = (rel & 3u) * 8u;
+  return shift ? (lo >> shift) | (hi << (32u - shift)) : lo;
+}
+
+__global__ __launch_bounds__(kThreads) void BytesChunkMapKernel(const uint8_t* __restrict__ s, uint64_t size,
+                                                                uint64_t* __restrict__ table,
+                                                                uint32_t* __restrict__ chunk_entry) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kMapChunk + 16];
+  __shared__ uint64_t node[kMapChunk];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kMapChunk;
+  if (threadIdx.x == 0) chunk_entry[blockIdx.x] = kNoEntry;
+  StageChunk(s, size, base, lds);
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < kMapChunk; e += kThreads) {
+    const uint64_t abs = base + e;
+    uint64_t t;
+    if (abs == size) {
+      t = MapNode(kMapExited, 0, kFlagEnd, e);
+    } else if (abs + 4 > size) {
+      t = MapNode(kMapExited, 0, kFlagBad, e);
+    } else {
+      const uint32_t len = LdsPrefix(lds, e);
+      if (len > size - (abs + 4)) {
+        t = MapNode(kMapExited, 0, kFlagBad, e);
+      } else {
+        const uint64_t q = static_cast<uint64_t>(e) + 4 + len;
+        t = q >= kMapChunk ? MapNode(kMapExited, 1, kFlagOk, q - kMapChunk) : MapNode(static_cast<uint32_t>(q), 1, kFlagOk, 0);
+      }
+    }
+    node[e] = t;
+  }
+  __syncthreads();
+  // Pointer jumping.  A node is one 64-bit LDS word, read and written whole, so rounds
+  // need no double buffering: whatever mix of old and new successors a lane sees, the
+  // invariant "count = headers from e up to, not including, next" holds.  At most
+  // kMapChunk/4 headers lie on a path, so 11 doublings always finish; usually far fewer.
+  for (int round = 0; round < 12; ++round) {
+    int pending = 0;
+    for (uint32_t e = threadIdx.x; e < kMapChunk; e += kThreads) {
+      const uint64_t t = node[e];
+      const uint32_t nx = NodeNext(t);
+      if (nx != kMapExited) {
+        const uint64_t u = node[nx];
+        node[e] = MapNode(NodeNext(u), NodeCount(t) + NodeCount(u), NodeFlag(u), NodePayload(u));
+        pending |= NodeNext(u) != kMapExited;
+      }
+    }
+    if (!__syncthreads_or(pending)) break;
+  }
+  uint64_t* out = table + base;
+  for (uint32_t e = threadIdx.x; e < kMapChunk; e += kThreads) out[e] = node[e];
+}
+
+__global__ void BytesChainKernel(const uint64_t* __restrict__ table, uint64_t size, uint64_t max_elems,
+                                 uint32_t* __restrict__ chunk_entry, uint64_t* __restrict__ chunk_first,
+                                 uint64_t* __restrict__ status) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint64_t pos = 0, count = 0;
+  int bad = 0;
+  while (count < max_elems && pos != size) {
+    const uint64_t c = pos / kMapChunk;
+    const uint32_t e = static_cast<uint32_t>(pos % kMapChunk);
+    const uint64_t t = table[c * kMapChunk + e];
+    chunk_entry[c] = e;
+    chunk_first[c] = count;
+    count += NodeCount(t);
+    const uint32_t flag = NodeFlag(t);
+    if (flag == kFlagOk) {
+      pos = (c + 1) * kMapChunk + NodePayload(t);
+    } else {
+      pos = c * kMapChunk + NodePayload(t);
+      bad = flag == kFlagBad && count < max_elems;  // a broken prefix past the requested elements is never looked at
+      break;
+    }
+  }
+  status[0] = count < max_elems ? count : max_elems;
+  status[1] = bad;
+  status[2] = pos;
+}
+
+__global__ __launch_bounds__(kThreads) void BytesChunkEmitKernel(const uint8_t* __restrict__ s, uint64_t size,
+                                                                 uint64_t max_elems,
+                                                                 const uint32_t* __restrict__ chunk_entry,
+                                                                 const uint64_t* __restrict__ chunk_first,
+                                                                 uint64_t* __restrict__ offsets,
+                                                                 uint32_t* __restrict__ lens) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kMapChunk + 16];
+  const uint32_t entry = chunk_entry[blockIdx.x];
+  if (entry == kNoEntry) return;  // uniform: the chain never starts an element in this chunk
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kMapChunk;
+  StageChunk(s, size, base, lds);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  uint64_t idx = chunk_first[blockIdx.x];
+  uint64_t p = entry;
+  while (p < kMapChunk && idx < max_elems) {
+    const uint64_t abs = base + p;
+    if (abs + 4 > size) break;  // clean end (abs == size) or a truncated prefix the chain kernel reported
+    const uint32_t len = LdsPrefix(lds, static_cast<uint32_t>(p));
+    if (len > size - (abs + 4)) break;
+    offsets[idx] = abs + 4;
+    lens[idx] = len;
+    ++idx;
+    p += 4 + static_cast<uint64_t>(len);
+  }
+}
+
 // ----------------------------------------------------------------- gather
 // One wavefront per element: lanes copy the payload with coalesced byte loads
 // and zero-fill the rest of the row.
@@ -257,6 +411,38 @@ int tca_bytes_index_launch(const uint8_t* stream_bytes, uint64_t size, uint64_t 
   if (!status || (size && !stream_bytes) || (max_elems && (!offsets || !lens))) return -1;
   hipLaunchKernelGGL(BytesIndexKernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), stream_bytes,
                      size, max_elems, offsets, lens, status);
+  return Status();
+}
+
+// Workspace of the parallel index: the chunk table (8 bytes per stream byte, rounded up to
+// whole chunks) followed by 4 + 8 bytes per chunk.
+uint64_t tca_bytes_index_workspace_bytes(uint64_t size) {
+  const uint64_t chunks = (size + kMapChunk - 1) / kMapChunk;
+  return chunks * kMapChunk * 8 + chunks * 8 + ((chunks * 4 + 7) & ~7ull);
+}
+
+// Same contract as tca_bytes_index_launch, with the walk spread over one workgroup per
+// 4 KiB of stream.  `workspace` (device memory, 8-byte aligned, at least
+// tca_bytes_index_workspace_bytes(size) bytes) needs no initialisation.
+int tca_bytes_index_parallel_launch(const uint8_t* stream_bytes, uint64_t size, uint64_t max_elems, uint64_t* offsets,
+                                    uint32_t* lens, uint64_t* status, void* workspace, uint64_t workspace_bytes,
+                                    void* stream) {
+  if (!status || (size && !stream_bytes) || (max_elems && (!offsets || !lens))) return -1;
+  const uint64_t chunks = (size + kMapChunk - 1) / kMapChunk;
+  if (chunks == 0 || chunks > 0x7FFFFFFFull)
+    return tca_bytes_index_launch(stream_bytes, size, max_elems, offsets, lens, status, stream);
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 7) || workspace_bytes < tca_bytes_index_workspace_bytes(size))
+    return -2;
+  auto* table = static_cast<uint64_t*>(workspace);
+  uint64_t* chunk_first = table + chunks * kMapChunk;
+  auto* chunk_entry = reinterpret_cast<uint32_t*>(chunk_first + chunks);
+  auto hs = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(BytesChunkMapKernel, dim3(static_cast<unsigned>(chunks)), dim3(kThreads), 0, hs, stream_bytes, size,
+                     table, chunk_entry);
+  hipLaunchKernelGGL(BytesChainKernel, dim3(1), dim3(64), 0, hs, table, size, max_elems, chunk_entry, chunk_first,
+                     status);
+  hipLaunchKernelGGL(BytesChunkEmitKernel, dim3(static_cast<unsigned>(chunks)), dim3(kThreads), 0, hs, stream_bytes, size,
+                     max_elems, chunk_entry, chunk_first, offsets, lens);
   return Status();
 }
 

@@ -51,6 +51,10 @@ int tca_bytes_pack_launch(const uint8_t* payload, const uint64_t* offsets, uint6
                           uint64_t out_bytes, void* stream);
 int tca_bytes_index_launch(const uint8_t* stream_bytes, uint64_t size, uint64_t max_elems, uint64_t* offsets,
                            uint32_t* lens, uint64_t* status, void* stream);
+uint64_t tca_bytes_index_workspace_bytes(uint64_t size);
+int tca_bytes_index_parallel_launch(const uint8_t* stream_bytes, uint64_t size, uint64_t max_elems, uint64_t* offsets,
+                                    uint32_t* lens, uint64_t* status, void* workspace, uint64_t workspace_bytes,
+                                    void* stream);
 int tca_bytes_gather_launch(const uint8_t* stream_bytes, const uint64_t* offsets, const uint32_t* lens, uint64_t n,
                             uint8_t* out, uint32_t pitch, void* stream);
 int tca_exclusive_scan_u64_launch(const uint32_t* lens, uint64_t n, uint32_t add_each, uint64_t* out,

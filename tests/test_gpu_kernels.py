@@ -140,6 +140,63 @@ def test_bytes_pack_index_gather(torch):
         codec.bytes_index(bad, 5)
 
 
+def _host_index(wire, max_elems):
+    offs, lens, pos = [], [], 0
+    while pos < len(wire) and len(offs) < max_elems:
+        if pos + 4 > len(wire):
+            raise ValueError("truncated prefix")
+        n = struct.unpack_from("<I", wire, pos)[0]
+        if n > len(wire) - pos - 4:
+            raise ValueError("truncated payload")
+        offs.append(pos + 4)
+        lens.append(n)
+        pos += 4 + n
+    return np.asarray(offs, dtype=np.int64), np.asarray(lens, dtype=np.int64)
+
+
+@pytest.mark.parametrize("case", ["short", "empty", "mixed", "huge", "boundary", "unaligned"])
+def test_bytes_index_chunk_parallel(torch, case):
+    """The chunk-parallel index (pointer jumping per 4 KiB chunk, one lookup per chunk,
+    per-chunk emit) against a host walk and the single-workgroup kernel."""
+    from triton_client_amd.ops import codec
+
+    rng = np.random.default_rng(11)
+    if case == "short":
+        sizes = rng.integers(1, 12, size=40000)
+    elif case == "empty":
+        sizes = np.zeros(5000, dtype=np.int64)  # 1024 prefixes per chunk: the longest path pointer jumping sees
+    elif case == "mixed":
+        sizes = rng.integers(0, 3000, size=800)
+    elif case == "huge":
+        sizes = np.array([3, 70000, 0, 5, 300000, 17, 1])  # elements that skip whole chunks
+    elif case == "boundary":
+        sizes = np.array([4092, 4092, 0, 4088, 1] + [60] * 64)  # prefixes exactly at / straddling chunk edges
+    else:
+        sizes = rng.integers(0, 50, size=20000)
+    wire = b"".join(struct.pack("<I", int(n)) + bytes(rng.integers(0, 256, size=int(n), dtype=np.uint8)) for n in sizes)
+    lead = 3 if case == "unaligned" else 0
+    dev = torch.from_numpy(np.frombuffer(b"x" * lead + wire, dtype=np.uint8).copy()).cuda()[lead:]
+    exp_o, exp_l = _host_index(wire, len(sizes))
+    o, l = codec.bytes_index(dev, len(sizes), parallel=True)
+    np.testing.assert_array_equal(o.cpu().numpy(), exp_o)
+    np.testing.assert_array_equal(l.cpu().numpy(), exp_l)
+    o1, l1 = codec.bytes_index(dev, len(sizes), parallel=False)
+    assert torch.equal(o, o1) and torch.equal(l, l1)
+    # fewer elements than the stream holds, more than it holds
+    k = max(1, len(sizes) // 3)
+    o2, l2 = codec.bytes_index(dev, k, parallel=True)
+    np.testing.assert_array_equal(o2.cpu().numpy(), exp_o[:k])
+    np.testing.assert_array_equal(l2.cpu().numpy(), exp_l[:k])
+    o3, _ = codec.bytes_index(dev, len(sizes) + 100, parallel=True)
+    assert len(o3) == len(sizes)
+    # malformed: last payload cut short, then a prefix cut short; a cut beyond the requested elements is ignored
+    for cut in (1, int(sizes[-1]) + 2):
+        with pytest.raises(ValueError):
+            codec.bytes_index(dev[: len(wire) - cut], len(sizes), parallel=True)
+    o4, _ = codec.bytes_index(dev[: len(wire) - 1], len(sizes) - 1, parallel=True)
+    np.testing.assert_array_equal(o4.cpu().numpy(), exp_o[:-1])
+
+
 def test_bf16_kernels(torch):
     import tritonclient.utils as utils
     from triton_client_amd.ops import codec

@@ -67,6 +67,11 @@ def install(lib):
     lib.tca_bytes_pack_launch.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p]
     lib.tca_bytes_index_launch.restype = c_int
     lib.tca_bytes_index_launch.argtypes = [c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.tca_bytes_index_workspace_bytes.restype = c_uint64
+    lib.tca_bytes_index_workspace_bytes.argtypes = [c_uint64]
+    lib.tca_bytes_index_parallel_launch.restype = c_int
+    lib.tca_bytes_index_parallel_launch.argtypes = [c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                    c_uint64, c_void_p]
     lib.tca_bytes_gather_launch.restype = c_int
     lib.tca_bytes_gather_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p]
     lib.tca_exclusive_scan_u64_launch.restype = c_int

@@ -54,22 +54,39 @@ def bytes_pack_from_lengths(payload, lengths):
     return bytes_pack(payload, lengths_to_offsets(lengths))
 
 
-def bytes_index(stream_bytes, max_elems):
+# streams longer than this are indexed by the chunk-parallel kernels (one workgroup per 4 KiB)
+PARALLEL_INDEX_MIN_BYTES = 32 << 10
+
+
+def bytes_index(stream_bytes, max_elems, parallel=None):
     """Walk a BYTES wire stream on the GPU.
 
     Returns ``(offsets int64 [count], lens int32 [count])`` of the payloads.
     Raises ``ValueError`` for a malformed stream.  At most ``max_elems``
-    elements are indexed (pass ``prod(shape)``).
+    elements are indexed (pass ``prod(shape)``).  ``parallel`` forces the
+    chunk-parallel (True) or the single-workgroup (False) kernel; by default
+    the stream length decides.
     """
     import torch
 
     dev = stream_bytes.device
+    size = stream_bytes.numel()
     offsets = torch.empty(max(1, max_elems), dtype=torch.int64, device=dev)
     lens = torch.empty(max(1, max_elems), dtype=torch.int32, device=dev)
     status = torch.zeros(3, dtype=torch.int64, device=dev)
-    rc = lib().tca_bytes_index_launch(stream_bytes.data_ptr(), stream_bytes.numel(), max_elems, offsets.data_ptr(),
-                                      lens.data_ptr(), status.data_ptr(), _stream())
-    check(rc, "tca_bytes_index_launch")
+    if parallel is None:
+        parallel = size >= PARALLEL_INDEX_MIN_BYTES
+    if parallel and size:
+        need = int(lib().tca_bytes_index_workspace_bytes(size))
+        work = torch.empty((need + 7) // 8, dtype=torch.int64, device=dev)
+        rc = lib().tca_bytes_index_parallel_launch(stream_bytes.data_ptr(), size, max_elems, offsets.data_ptr(),
+                                                   lens.data_ptr(), status.data_ptr(), work.data_ptr(), work.numel() * 8,
+                                                   _stream())
+        check(rc, "tca_bytes_index_parallel_launch")
+    else:
+        rc = lib().tca_bytes_index_launch(stream_bytes.data_ptr(), size, max_elems, offsets.data_ptr(),
+                                          lens.data_ptr(), status.data_ptr(), _stream())
+        check(rc, "tca_bytes_index_launch")
     count, bad, cursor = (int(v) for v in status.tolist())
     if bad:
         raise ValueError(f"malformed BYTES tensor near offset {cursor}")
