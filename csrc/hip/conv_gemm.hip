@@ -103,7 +103,8 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
                                                           const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ Y, int M, int N, int K, int relu,
                                                           RowMap map, int tiles_n, int xcd_chunk, unsigned x_bytes,
-                                                          int stages) {
+                                                          int stages, int splits, float* __restrict__ partials,
+                                                          unsigned* __restrict__ arrivals) {
   constexpr int kW = 2 * kWN;                // wavefronts: 2 along m x kWN along n
   constexpr int kT = 64 * kW;                // threads
   constexpr int kAVecs = BM * 8 / kT;        // 16-byte vectors per thread and stage (activation tile)
@@ -183,8 +184,23 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
   const __amdgpu_buffer_rsrc_t x_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(X) - lead, 0, static_cast<int>(x_bytes + 2u * lead), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(W), 0, N * K * 2, 0x00020000);
+  // Split-K: blockIdx.y takes a contiguous run of the K steps (host: every run is non-empty)
+  int kt_begin = 0;
+  int ktiles = K / kBK;
+  if (splits > 1) {
+    const int per = (ktiles + splits - 1) / splits;
+    kt_begin = static_cast<int>(blockIdx.y) * per;
+    ktiles = ktiles - kt_begin < per ? ktiles - kt_begin : per;
+  }
   // position of the NEXT K step to issue (steps are issued strictly in order)
-  int next_k0 = 0, next_c0 = 0, next_kh = 0, next_kw = 0, next_tap = 0;
+  int next_k0 = kt_begin * kBK, next_c0 = 0, next_kh = 0, next_kw = 0, next_tap = 0;
+  if constexpr (kSpatial) {
+    const int per_tap = map.cin / kBK;
+    next_tap = kt_begin / per_tap;
+    next_c0 = (kt_begin - next_tap * per_tap) * kBK;
+    next_kh = next_tap / map.ksize;
+    next_kw = next_tap - next_kh * map.ksize;
+  }
   auto issue_tile = [&](int stage) {
     _Float16* base = lds + stage * kStageHalfs;
     if constexpr (kSpatial) {
@@ -290,7 +306,6 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
 #pragma unroll
     for (int mi = 0; mi < kMI; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
 
-  const int ktiles = K / kBK;
   // fragment addressing: lane -> (row lane&15, 16-byte chunk lane>>4 [+4 for the second
   // half of the K step]); the row swizzle only depends on lane&15 because every
   // fragment starts at a multiple of 16 rows, and "+4 chunks" is an XOR of 32 halfs
@@ -339,12 +354,12 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
       stage = stage + 1 == stages ? 0 : stage + 1;
     }
   } else {
-    load_tile(0);
+    load_tile(kt_begin);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < ktiles; ++kt) {
       const bool more = kt + 1 < ktiles;
-      if (more) load_tile(kt + 1);  // in flight while the MFMAs below run
+      if (more) load_tile(kt_begin + kt + 1);  // in flight while the MFMAs below run
       compute_tile(stages == 2 ? (kt & 1) : 0);
       if (more) {
         store_tile((kt + 1) & 1);  // the other stage: last read one iteration ago, behind a barrier
@@ -353,6 +368,71 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     }
   }
   __syncthreads();  // every wave is done reading the operand stages: reuse them for the output tile
+
+  if (splits > 1) {
+    // Split-K fix-up in the same launch: every block parks its fp32 partial tile in the
+    // register layout (coalesced 8-byte stores per lane and fragment), then takes a ticket
+    // for its output tile; the block that draws the last ticket adds the partials up in
+    // split order (bit-reproducible whichever block that is) and runs the epilogue.  The
+    // ticket counter is back at zero when the launch ends.
+    //
+    // Blocks of one tile run on different XCDs, whose L2s are not coherent with each other
+    // for ordinary accesses.  A device-scope fence would make them so by writing back the
+    // whole L2 - tens of microseconds with the previous layer's output still dirty in it.
+    // Instead the partials themselves move with device-scope relaxed atomic stores and
+    // loads (write-through / cache-bypassing accesses), ordered against the ticket by
+    // waiting for the stores' acknowledgements.
+    constexpr int kFrags = kNI * kMI;
+    using u64 = unsigned long long;
+    u64* tile_partials = reinterpret_cast<u64*>(partials) + static_cast<size_t>(bid) * splits * (kFrags * kT * 2);
+    u64* mine = tile_partials + static_cast<size_t>(blockIdx.y) * (kFrags * kT * 2);
+#pragma unroll
+    for (int ni = 0; ni < kNI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < kMI; ++mi) {
+        const float4v a = acc[ni][mi];
+        u64* dst = mine + ((ni * kMI + mi) * 2) * kT + tid;
+        __hip_atomic_store(dst, (static_cast<u64>(__float_as_uint(a[1])) << 32) | __float_as_uint(a[0]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + kT, (static_cast<u64>(__float_as_uint(a[3])) << 32) | __float_as_uint(a[2]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's partial has reached device-coherent memory
+    __syncthreads();                                  // ... and so has every lane's
+    // the verdict travels through the first word of the (now idle) operand stages: a static
+    // __shared__ variable would count against the 160 KiB the largest tiles ask for
+    int* verdict = reinterpret_cast<int*>(lds);
+    if (tid == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(&arrivals[bid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == static_cast<unsigned>(splits - 1);
+      *verdict = last;
+      // every block of this tile has drawn: ready for the next launch
+      if (last) __hip_atomic_store(&arrivals[bid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int is_last = *verdict;
+    __syncthreads();  // everyone has read it before the epilogue below overwrites the stages
+    if (!is_last) return;
+#pragma unroll
+    for (int ni = 0; ni < kNI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < kMI; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < splits; ++sp) {
+      const u64* part = tile_partials + static_cast<size_t>(sp) * (kFrags * kT * 2);
+#pragma unroll
+      for (int ni = 0; ni < kNI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < kMI; ++mi) {
+          const u64* src = part + ((ni * kMI + mi) * 2) * kT + tid;
+          const u64 lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const u64 hi = __hip_atomic_load(src + kT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[ni][mi][0] += __uint_as_float(static_cast<unsigned>(lo));
+          acc[ni][mi][1] += __uint_as_float(static_cast<unsigned>(lo >> 32));
+          acc[ni][mi][2] += __uint_as_float(static_cast<unsigned>(hi));
+          acc[ni][mi][3] += __uint_as_float(static_cast<unsigned>(hi >> 32));
+        }
+    }
+  }
 
   // accumulator (+bias, fp32) -> LDS as fp16 [BM][kCPitch]; D^T layout: lane holds
   // pixel m = lane&15 and channels n = 4*(lane>>4) .. +3 of each fragment
@@ -678,14 +758,45 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
   }
 }
 
+struct SplitK {
+  int splits;                        // 1 = off, 0 = let the launcher decide, n = exactly n runs of the K loop
+  float* partials;                   // workspace of the partial tiles
+  unsigned long long partial_bytes;
+  unsigned* arrivals;                // one zero-initialised counter per output tile
+  int arrival_slots;
+};
+
 template <int BM, int BN, int kWN, bool kSpatial, bool kGlds>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
-                  int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, hipStream_t st) {
+                  int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, const SplitK& sk,
+                  hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = N / BN;
   const int blocks = tiles_m * tiles_n;
   const int xcd_chunk = (blocks % 8 == 0) ? blocks / 8 : 0;  // the remap must be a bijection
-  const int ktiles = K / kBK;
+  const int ktiles_all = K / kBK;
+  // split-K: requested, or (0) chosen here - when the tiles alone leave half of the 256 CUs
+  // idle and the K loop is long enough (32 steps measured: the fix-up costs 3-4 us) to
+  // share out; bounded by the caller's workspace
+  int splits = sk.splits;
+  if (splits == 0) {
+    splits = 1;
+    if (sk.partials != nullptr && blocks <= 128 && ktiles_all >= 32) {
+      splits = 256 / blocks;
+      if (splits > ktiles_all / 4) splits = ktiles_all / 4;
+      if (splits > 8) splits = 8;
+    }
+  }
+  if (splits > ktiles_all) splits = ktiles_all;
+  while (splits > 1 && (splits - 1) * ((ktiles_all + splits - 1) / splits) >= ktiles_all) --splits;  // no empty run
+  if (splits > 1) {
+    const unsigned long long need = static_cast<unsigned long long>(blocks) * splits * BM * BN * sizeof(float);
+    if (sk.partials == nullptr || sk.arrivals == nullptr || need > sk.partial_bytes || blocks > sk.arrival_slots) {
+      if (sk.splits > 1) return -4;  // asked for explicitly: the workspace must hold it
+      splits = 1;
+    }
+  }
+  const int ktiles = (ktiles_all + splits - 1) / splits;
   if (!kGlds) stages = 2;
   if (stages > ktiles) stages = ktiles;
   size_t lds_bytes = static_cast<size_t>(stages) * (BM + BN) * kBK * sizeof(_Float16);
@@ -697,8 +808,8 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
   }
-  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds>), dim3(blocks), dim3(128 * kWN), lds_bytes, st, x, w, bias, residual, y, M,
-                     N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages);
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st, x, w, bias,
+                     residual, y, M, N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages, splits, sk.partials, sk.arrivals);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
 }
@@ -712,9 +823,13 @@ extern "C" {
 // variant: low 4 bits 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile (4 wavefronts),
 // 4 = 128x128, 5 = 256x128 (8 wavefronts);
 // bit 4 selects register staging; bits 5-6 the number of LDS stages (2 or 3).
-int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
-                         int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu, int variant,
-                         void* stream) {
+// splits: 1 = no split-K, 0 = automatic, n > 1 = exactly n.  partials / arrivals: the split-K
+// workspace (device memory; `arrivals` zero-filled once, the kernel leaves it zeroed) -
+// one workspace per stream that launches concurrently.
+int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                                int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu,
+                                int variant, int splits, void* partials, unsigned long long partial_bytes,
+                                void* arrivals, int arrival_slots, void* stream) {
   if (!x || !w || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || stride <= 0 || ksize <= 0 || pad < 0) return -1;
   if (cin % kBK != 0 || cout % 64 != 0) return -2;  // whole K steps inside one tap, whole n tiles
   const int oh = (in_h + 2 * pad - ksize) / stride + 1;
@@ -768,6 +883,8 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
     const long long per_cu_with_3 = (160 * 1024) / (3 * (bm + bn) * kBK * 2);
     stages = per_cu_wanted <= per_cu_with_3 ? 3 : 2;
   }
+  if (splits < 0 || (reinterpret_cast<uintptr_t>(partials) & 15)) return -1;
+  const SplitK sk{splits, static_cast<float*>(partials), partial_bytes, static_cast<unsigned*>(arrivals), arrival_slots};
   auto st = static_cast<hipStream_t>(stream);
   auto xp = static_cast<const _Float16*>(x);
   auto wp = static_cast<const _Float16*>(w);
@@ -776,10 +893,10 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
   auto yp = static_cast<_Float16*>(y);
   // staging: direct-to-LDS DMA by default; `staging` = 1 keeps the register-staged path (A/B testing)
 #define TCA_DISPATCH(BM_, BN_, WN_)                                                                                      \
-  (spatial ? (staging ? LaunchConvGemm<BM_, BN_, WN_, true, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)  \
-                      : LaunchConvGemm<BM_, BN_, WN_, true, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st))  \
-           : (staging ? LaunchConvGemm<BM_, BN_, WN_, false, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st) \
-                      : LaunchConvGemm<BM_, BN_, WN_, false, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, st)))
+  (spatial ? (staging ? LaunchConvGemm<BM_, BN_, WN_, true, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, sk, st)  \
+                      : LaunchConvGemm<BM_, BN_, WN_, true, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, sk, st))  \
+           : (staging ? LaunchConvGemm<BM_, BN_, WN_, false, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, sk, st) \
+                      : LaunchConvGemm<BM_, BN_, WN_, false, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, sk, st)))
   switch (variant) {
     case 1: return TCA_DISPATCH(128, 128, 2);
     case 2: return TCA_DISPATCH(128, 64, 2);
@@ -792,6 +909,13 @@ int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const v
     default: return -3;
   }
 #undef TCA_DISPATCH
+}
+
+int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                         int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu, int variant,
+                         void* stream) {
+  return tca_conv_gemm_splitk_launch(x, w, bias, residual, y, batch, in_h, in_w, ksize, stride, pad, cin, cout, relu,
+                                     variant, 1, nullptr, 0, nullptr, 0, stream);
 }
 
 int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,

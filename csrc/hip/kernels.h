@@ -80,6 +80,10 @@ int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const voi
 int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                          int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu, int variant,
                          void* stream);
+int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                                int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu,
+                                int variant, int splits, void* partials, unsigned long long partial_bytes,
+                                void* arrivals, int arrival_slots, void* stream);
 // n (source, destination, size) device copies in one launch (64 per kernel).
 int tca_batched_copy_launch(const void* const* srcs, void* const* dsts, const uint64_t* bytes, int n, void* stream);
 int tca_bias_act_launch(void* y, const void* bias, const void* residual, long long rows, int channels, int relu,

@@ -386,6 +386,42 @@ def test_conv3x3_exact_integer_taps(torch):
             assert torch.equal(got.float(), ref), (variant, staging)
 
 
+@pytest.mark.parametrize("staging", ["lds2", "lds3", "reg"])
+def test_conv_split_k_exact_and_repeatable(torch, staging):
+    """Split-K (several blocks per output tile, partials summed by the block that arrives
+    last): integer data must give the exact sums for every split count, tile variant and
+    staging path; launching again must work (the arrival counters are back at zero); the
+    result must not depend on which block arrives last."""
+    from triton_client_amd.ops import conv
+
+    # 3x3, stride 2, two K steps per tap (18 K steps): runs that start in the middle of a tap
+    x = _nhwc(torch.randint(-2, 3, (3, 128, 10, 7), device="cuda").half())
+    wt = _nhwc(torch.randint(-1, 2, (128, 128, 3, 3), device="cuda").half())
+    wt[7, 70, 2, 0] = 3.0
+    bias = torch.randint(-3, 4, (128,), device="cuda").half()
+    ref = torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=2, padding=1)
+    res = _nhwc(torch.randint(-2, 3, tuple(ref.shape), device="cuda").half())
+    ref = (ref + res.float()).clamp_min(0)
+    for variant in ("64x64", "64x64w8", "128x64", "128x128w8"):
+        for splits in (0, 2, 3, 5, 18, 64):  # 64 > K steps: clamped
+            for _ in range(2):
+                got = conv.conv2d(x, wt, bias, res, relu=True, stride=2, padding=1, variant=variant, staging=staging,
+                                  split_k=splits)
+                assert torch.equal(got.float(), ref), (variant, splits)
+    # 1x1 with a long K loop and few tiles (the shape split-K is for), fp16 data: bit-identical across repeats
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = _nhwc(torch.randn(8, 2048, 7, 7, device="cuda", generator=gen).half())
+    w1 = (torch.randn(512, 2048, device="cuda", generator=gen) / 2048 ** 0.5).half()
+    b1 = torch.randn(512, device="cuda", generator=gen).half()
+    want = torch.nn.functional.conv2d(x.float(), w1.float().reshape(512, 2048, 1, 1), b1.float()).clamp_min(0)
+    first = conv.conv1x1(x, w1, b1, None, relu=True, staging=staging, split_k=4)
+    torch.testing.assert_close(first.float(), want, rtol=4e-3, atol=4e-3)
+    for _ in range(5):
+        assert torch.equal(conv.conv1x1(x, w1, b1, None, relu=True, staging=staging, split_k=4), first)
+    auto = conv.conv1x1(x, w1, b1, None, relu=True, staging=staging)
+    torch.testing.assert_close(auto.float(), want, rtol=4e-3, atol=4e-3)
+
+
 def test_batched_copy_many_entries_and_alignments(torch):
     from triton_client_amd.ops.copy import batched_copy
 

@@ -91,6 +91,10 @@ def install(lib):
     lib.tca_conv_gemm_launch.restype = c_int
     lib.tca_conv_gemm_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.tca_conv_gemm_splitk_launch.restype = c_int
+    lib.tca_conv_gemm_splitk_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                c_uint64, c_void_p, c_int, c_void_p]
     lib.tca_batched_copy_launch.restype = c_int
     lib.tca_batched_copy_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p]
     lib.tca_bias_act_launch.restype = c_int

@@ -40,16 +40,44 @@ def _variant_code(variant, staging=None):
     return code | (int(staging[3:]) << 5 if len(staging) > 3 else 0)
 
 
-def gemm_pays(pixels, cout, k_total):
+def gemm_pays(pixels, cout, k_total, split_k=None):
     """Whether the MFMA GEMM kernel beats library convolution + epilogue pass
-    for a layer with ``pixels`` output pixels.  The kernel has no split-K: with
-    few 64x64 output tiles and a long K loop every CU runs at most one block and
-    the kernel time is the K loop's latency chain (about a third of a microsecond
-    per 64-wide K step), which is where the library's split-K kernels win.
-    Thresholds fitted to per-layer timings on MI355X (``tools/conv_bench.py``)."""
+    for a layer with ``pixels`` output pixels.  With split-K (the default) it
+    always does on the layers measured (``tools/conv_bench.py``).  Without it,
+    few 64x64 output tiles and a long K loop mean every CU runs at most one block
+    and the kernel time is the K loop's latency chain (about a third of a
+    microsecond per 64-wide K step), which is where the library's own split-K
+    kernels win."""
+    if SPLIT_K if split_k is None else split_k:
+        return True
     tiles = ((pixels + 63) // 64) * (cout // 64)
     ksteps = k_total // 64
     return ksteps <= 40 or tiles >= 2.5 * ksteps
+
+
+# Split-K (A/B switch): layers whose output tiles fill less than half of the CUs share
+# their K loop out over several blocks per tile, summed inside the same launch.
+SPLIT_K = __import__("os").environ.get("TCA_CONV_SPLITK", "1") != "0"
+_SPLITK_PARTIAL_BYTES = 32 << 20   # 128 tiles x 8 runs x 64x64 fp32 = 16 MiB; room for 128x128 tiles
+_SPLITK_ARRIVAL_SLOTS = 4096
+_splitk_workspaces = {}
+
+
+def _splitk_workspace(device):
+    """Per-stream workspace of the split-K fix-up: partial tiles and one arrival
+    counter per output tile (zeroed once; the kernel leaves it zeroed).  Launches on
+    one stream are ordered, so they share it; another stream (another execution
+    instance of a model, with its own captured graphs) gets its own."""
+    import torch
+
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _splitk_workspaces.get(key)
+    if ws is None:
+        # allocated outside any graph capture pool on purpose: the tensors live as long as the process
+        partials = torch.empty(_SPLITK_PARTIAL_BYTES // 4, dtype=torch.float32, device=device)
+        arrivals = torch.zeros(_SPLITK_ARRIVAL_SLOTS, dtype=torch.int32, device=device)
+        ws = _splitk_workspaces[key] = (partials, arrivals)
+    return ws
 
 
 def _stream():
@@ -64,7 +92,26 @@ def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
 
-def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0, out=None, staging=None):
+def _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, cout, relu, variant, staging, split_k):
+    """``split_k``: None = automatic when enabled (``SPLIT_K``), 1 = off, n > 1 = exactly n."""
+    code = _variant_code(variant, staging)
+    splits = (0 if SPLIT_K else 1) if split_k is None else int(split_k)
+    if splits == 1:
+        partials = arrivals = None
+    else:
+        partials, arrivals = _splitk_workspace(x.device)
+    rc = lib().tca_conv_gemm_splitk_launch(
+        x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+        residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, int(r), int(stride),
+        int(padding), cin, cout, 1 if relu else 0, code, splits,
+        partials.data_ptr() if partials is not None else None, partials.numel() * 4 if partials is not None else 0,
+        arrivals.data_ptr() if arrivals is not None else None, arrivals.numel() if arrivals is not None else 0,
+        _stream())
+    check(rc, "tca_conv_gemm_splitk_launch")
+
+
+def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0, out=None, staging=None,
+            split_k=None):
     """``act(conv1x1(x, weight) + bias (+ residual))``.
 
     x        fp16 ``[N, Cin, H, W]`` channels-last
@@ -94,16 +141,12 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0
         raise ValueError("residual must match the output (fp16, channels-last)")
     if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
-    code = _variant_code(variant, staging)
-    rc = lib().tca_conv1x1_launch(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                  residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w,
-                                  int(stride), cin, cout, 1 if relu else 0, code, _stream())
-    check(rc, "tca_conv1x1_launch")
+    _launch(x, weight, bias, residual, out, n, h, w, 1, stride, 0, cin, cout, relu, variant, staging, split_k)
     return out
 
 
 def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0, variant=0, out=None,
-           staging=None):
+           staging=None, split_k=None):
     """``act(conv2d(x, weight) + bias (+ residual))`` as an implicit GEMM on the
     MFMA kernel (square kernels, e.g. 3x3 with padding 1).
 
@@ -135,11 +178,7 @@ def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0,
         raise ValueError("residual must match the output (fp16, channels-last)")
     if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
-    code = _variant_code(variant, staging)
-    rc = lib().tca_conv_gemm_launch(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                    residual.data_ptr() if residual is not None else None, out.data_ptr(), n, h, w, r,
-                                    int(stride), int(padding), cin, cout, 1 if relu else 0, code, _stream())
-    check(rc, "tca_conv_gemm_launch")
+    _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, cout, relu, variant, staging, split_k)
     return out
 
 
