@@ -32,6 +32,7 @@ def _np_bytes(values, shape):
 @register
 class Simple(Model):
     name = "simple"
+    inline = True  # microseconds of host work: transports may run it on their own thread
     max_batch_size = 8
     inputs = [TensorSpec("INPUT0", "INT32", [16]), TensorSpec("INPUT1", "INT32", [16])]
     outputs = [TensorSpec("OUTPUT0", "INT32", [16]), TensorSpec("OUTPUT1", "INT32", [16])]
@@ -47,6 +48,7 @@ class SimpleInt8(Model):
     ``src/python/examples/grpc_explicit_int8_content_client.py:59``)."""
 
     name = "simple_int8"
+    inline = True  # microseconds of host work: transports may run it on their own thread
     max_batch_size = 8
     inputs = [TensorSpec("INPUT0", "INT8", [16]), TensorSpec("INPUT1", "INT8", [16])]
     outputs = [TensorSpec("OUTPUT0", "INT8", [16]), TensorSpec("OUTPUT1", "INT8", [16])]
@@ -78,6 +80,7 @@ class VersionedAddSub(Model):
 @register
 class SimpleString(Model):
     name = "simple_string"
+    inline = True  # microseconds of host work: transports may run it on their own thread
     max_batch_size = 8
     inputs = [TensorSpec("INPUT0", "BYTES", [16]), TensorSpec("INPUT1", "BYTES", [16])]
     outputs = [TensorSpec("OUTPUT0", "BYTES", [16]), TensorSpec("OUTPUT1", "BYTES", [16])]
@@ -98,6 +101,7 @@ class SimpleString(Model):
 @register
 class SimpleIdentity(Model):
     name = "simple_identity"
+    inline = True  # microseconds of host work: transports may run it on their own thread
     max_batch_size = 8
     inputs = [TensorSpec("INPUT0", "BYTES", [-1])]
     outputs = [TensorSpec("OUTPUT0", "BYTES", [-1])]

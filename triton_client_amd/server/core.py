@@ -754,6 +754,18 @@ class InferenceCore:
             lm = self._loaded.get(name)
         return lm is not None and lm.batcher is not None
 
+    def runs_inline(self, name):
+        """Whether a transport's event loop may run ``name`` itself instead of handing the
+        request to a worker thread: a stateless CPU model that answers in microseconds
+        (``inline = True`` on the model class) with no delay / fault-injection parameters."""
+        with self._lock:
+            lm = self._loaded.get(name)
+        if lm is None:
+            return False
+        model = lm.model
+        return bool(getattr(model, "inline", False)) and model.device == "cpu" and not model.parameters \
+            and not model.decoupled
+
     def infer(self, req: InferRequest, on_done=None):
         """Run one request.  Returns an :class:`InferResponse` for ordinary
         models, or an iterator of them for decoupled models.

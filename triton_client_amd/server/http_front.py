@@ -23,7 +23,7 @@ from urllib.parse import parse_qs, unquote, urlsplit
 
 import numpy as np
 
-from .core import InferRequest, InputTensor, RequestedOutput, ServerError, ShmRef, encode_wire
+from .core import ASYNC, InferRequest, InputTensor, RequestedOutput, ServerError, ShmRef, encode_wire
 
 _REASONS = {200: "OK", 400: "Bad Request", 404: "Not Found", 405: "Method Not Allowed", 500: "Internal Server Error",
             503: "Service Unavailable"}
@@ -378,7 +378,31 @@ class HttpFront:
         hl = headers.get("inference-header-content-length")
         req = parse_infer_body(model, version, body, int(hl) if hl is not None else None)
         loop = asyncio.get_running_loop()
-        resp = await loop.run_in_executor(self.pool, self.core.infer, req)
+        if self.core.uses_batcher(model):
+            # GPU model behind the dynamic batcher: queue from this thread, the completer
+            # thread hands the outcome back to the loop - no pool thread parked per request
+            fut = loop.create_future()
+
+            def settle(response, error):
+                if fut.done():
+                    return
+                if error is not None:
+                    fut.set_exception(error)
+                else:
+                    fut.set_result(response)
+
+            def done(response, error):
+                loop.call_soon_threadsafe(settle, response, error)
+
+            resp = self.core.infer(req, on_done=done)
+            if resp is ASYNC:
+                resp = await fut
+        elif self.core.runs_inline(model):
+            # microsecond-scale CPU model without delay / fault knobs: two thread hand-offs
+            # would cost several times the inference
+            resp = self.core.infer(req)
+        else:
+            resp = await loop.run_in_executor(self.pool, self.core.infer, req)
         if not hasattr(resp, "outputs"):
             raise ServerError(
                 f"model '{model}' is decoupled and can only be used through the gRPC streaming API", 400)

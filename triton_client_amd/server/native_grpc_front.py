@@ -124,8 +124,8 @@ class NativeGrpcFront:
             except Exception as e:
                 self._front.finish(call, _INVALID_ARGUMENT, f"malformed ModelInferRequest: {e}")
                 return
-            if self.core.uses_batcher(req.model_name):
-                self._infer(call, req)  # queues and returns
+            if self.core.uses_batcher(req.model_name) or self.core.runs_inline(req.model_name):
+                self._infer(call, req)  # queues and returns / answers within microseconds
             else:
                 self._pool.submit(self._infer, call, req)
             return
