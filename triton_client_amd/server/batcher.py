@@ -101,6 +101,7 @@ class DynamicBatcher:
         # per instance: [ring of [pinned uint8 buffer, event of its last H2D copy, bytes used], next entry]
         self._pinned = [[[], 0] for _ in range(self.instances)]
         self._pinned_bytes = 0
+        self._upload = [None] * self.instances  # per instance: copy stream + device-side staging buffers
         self.q = queue.Queue()
         self.completions = [queue.Queue() for _ in range(self.instances)]
         self._held = None
@@ -324,7 +325,7 @@ class DynamicBatcher:
                 dev_inputs = core._to_device(lm, {k: v for k, v in it.inputs.items() if k != in_name}, it.stable)
                 x_dtype = torch.from_numpy(host_x[:0].copy()).dtype
                 sbuf, _ = self._static_buffers(inst, it.batch, in_name, x_dtype, tuple(host_x.shape[1:]), out_name)
-                self._stage_many([(host_x, sbuf)], stream, inst)
+                self._stage_wire([(host_x, 0, it.batch)], sbuf, stream, inst)
                 dev_inputs[in_name] = sbuf
             else:
                 dev_inputs = core._to_device(lm, it.inputs, it.stable)
@@ -371,13 +372,13 @@ class DynamicBatcher:
                 for it in group:
                     x = it.inputs[in_name]
                     if isinstance(x, np.ndarray):
-                        host_pairs.append((x, sbuf[row: row + it.batch]))
+                        host_pairs.append((x, row, it.batch))
                     elif x.is_cuda and x.is_contiguous() and x.dtype == sbuf.dtype:
                         gather.append((x.data_ptr(), sbuf.data_ptr() + row * row_bytes, it.batch * row_bytes))
                     else:
                         sbuf[row: row + it.batch].copy_(x, non_blocking=True)
                     row += it.batch
-            self._stage_many(host_pairs, stream, inst)
+            self._stage_wire(host_pairs, sbuf, stream, inst)
             batched_copy(gather, stream)
             merged = {in_name: sbuf, "__out__" + out_name: obuf, "__instance__": inst}
             out = model.execute(merged, group[0].ctx)[out_name]
@@ -385,6 +386,7 @@ class DynamicBatcher:
             row = 0
             out_row_bytes = out[0].numel() * out.element_size()
             scatter = []
+            host_all = None  # the whole output batch in page-locked memory: ONE D2H copy for all wire answers
             for it in group:
                 piece = out[row: row + it.batch]
                 dev_inputs = {}
@@ -403,26 +405,36 @@ class DynamicBatcher:
                 row += it.batch
                 if placed:
                     result = {out_name: dev_inputs["__out__" + out_name]}
-                else:
+                elif any(ro.class_count for ro in it.requested):
                     result = self._host_copies(it, {out_name: piece}, stream, own_static=True)
+                else:
+                    if host_all is None:
+                        host_all = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+                        with torch.cuda.stream(stream):
+                            host_all.copy_(out, non_blocking=True)
+                    result = {out_name: host_all[row - it.batch: row]}
                 pending.append((it, dev_inputs, result))
             batched_copy(scatter, stream)
         event = torch.cuda.Event()
         event.record(stream)
         self.completions[inst].put((event, pending, total, t_exec, time.perf_counter_ns()))
 
-    def _stage_many(self, pairs, stream, inst):
-        """Host arrays -> device tensors through a ring of pinned buffers: one CPU
-        memcpy per array into page-locked memory, then asynchronous H2D copies on the
-        model stream.  A copy from pageable memory would be staged by the
-        runtime in small synchronous chunks on this thread instead.  A ring entry is
-        reused only after the H2D copies that read it have finished; every execution
-        instance has its own ring because those copies run on its stream."""
+    def _stage_wire(self, items, sbuf, stream, inst):
+        """Wire tensors ``[(host array, first row, rows), ...]`` -> rows of the static input
+        buffer ``sbuf`` that the captured graph reads.
+
+        Host side: one CPU memcpy per array into a small ring of page-locked buffers (a copy
+        from pageable memory would be staged by the runtime in small synchronous chunks on
+        this thread), then an asynchronous H2D copy.  The H2D copies run on the instance's
+        COPY stream into a device-side staging buffer, and the compute stream only does a
+        device-to-device copy of the finished rows (microseconds) once they have landed: the
+        upload of the next batch overlaps the forward of the current one instead of queueing
+        behind it on the compute stream, and the pinned ring is recycled at H2D speed."""
         import torch
 
-        if not pairs:
+        if not items:
             return
-        srcs = [torch.from_numpy(np.ascontiguousarray(arr)) for arr, _ in pairs]
+        srcs = [torch.from_numpy(np.ascontiguousarray(arr)) for arr, _, _ in items]
         sizes = [t.numel() * t.element_size() for t in srcs]
         state = self._pinned[inst]
         ring = state[0]
@@ -437,12 +449,27 @@ class DynamicBatcher:
             self._pinned_bytes = per_entry
             ring[:] = [[torch.empty(per_entry, dtype=torch.uint8, pin_memory=True), None, 0] for _ in range(4)]
             state[1] = 0
+        up = self._upload[inst]
+        if up is None or up["bufs"][0].dtype != sbuf.dtype or tuple(up["bufs"][0].shape[1:]) != tuple(sbuf.shape[1:]):
+            device = sbuf.device
+            up = self._upload[inst] = {
+                "stream": torch.cuda.Stream(device=device),
+                "bufs": [torch.empty((self.max_batch, *sbuf.shape[1:]), dtype=sbuf.dtype, device=device) for _ in range(2)],
+                "free": [None, None],  # event after the compute stream's last read of each buffer
+                "next": 0,
+            }
+        slot = up["next"]
+        up["next"] = slot ^ 1
+        dev = up["bufs"][slot]
+        copy_stream = up["stream"]
+        if up["free"][slot] is not None:
+            copy_stream.wait_event(up["free"][slot])  # GPU-side: the batch that used this buffer two uploads ago
         # One tensor at a time: reserve a ring slot (waiting for the H2D copy that last read
         # it), memcpy, issue the H2D copy, mark the slot.  Serial memcpys on purpose (a thread
         # pool here was measured to halve the wire throughput: the extra threads fight the
         # transport callbacks for the GIL); the DMA of one tensor overlaps the memcpy of the next.
-        with torch.cuda.stream(stream):
-            for (_, dst), src, nbytes in zip(pairs, srcs, sizes):
+        with torch.cuda.stream(copy_stream):
+            for (_, row, rows), src, nbytes in zip(items, srcs, sizes):
                 entry = ring[state[1]]
                 if entry[1] is None or entry[2] + nbytes > entry[0].numel():
                     if entry[1] is not None:  # full: move on and wait for the next entry's last reader
@@ -456,8 +483,24 @@ class DynamicBatcher:
                 host = entry[0][off: off + nbytes].view(src.dtype).view(src.shape)
                 entry[2] = (off + nbytes + 255) & ~255
                 host.copy_(src)
-                dst.copy_(host, non_blocking=True)
-                entry[1].record(stream)  # the latest reader of this entry
+                dev[row: row + rows].copy_(host, non_blocking=True)
+                entry[1].record(copy_stream)  # the latest reader of this entry
+        landed = torch.cuda.Event()
+        landed.record(copy_stream)
+        stream.wait_event(landed)
+        with torch.cuda.stream(stream):
+            # merge neighbouring row ranges: a batch made only of wire requests is one copy
+            run_start, run_end = items[0][1], items[0][1] + items[0][2]
+            for _, row, rows in items[1:]:
+                if row == run_end:
+                    run_end = row + rows
+                    continue
+                sbuf[run_start:run_end].copy_(dev[run_start:run_end], non_blocking=True)
+                run_start, run_end = row, row + rows
+            sbuf[run_start:run_end].copy_(dev[run_start:run_end], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(stream)
+        up["free"][slot] = done
 
     def _host_copies(self, it, result, stream, own_static):
         """Enqueue D2H copies (pinned) for outputs that go back over the wire,
