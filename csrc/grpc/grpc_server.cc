@@ -197,7 +197,19 @@ struct GrpcServerFront::Reactor {
     auto it = c->streams.find(stream);
     if (it == c->streams.end()) return;
     StreamState* s = &it->second;
-    if (len) s->rbuf.append(reinterpret_cast<const char*>(data), len);
+    if (len) {
+      if (s->rbuf.size() < 5 && s->rbuf.size() + len >= 5) {
+        // the length prefix is complete: size the buffer for the whole message once instead of
+        // growing (and copying) it through the doublings of a megabyte-sized tensor
+        uint8_t prefix[5];
+        const size_t have = s->rbuf.size();
+        for (size_t i = 0; i < 5; ++i) prefix[i] = i < have ? static_cast<uint8_t>(s->rbuf[i]) : data[i - have];
+        const size_t n = (static_cast<size_t>(prefix[1]) << 24) | (static_cast<size_t>(prefix[2]) << 16) |
+                         (static_cast<size_t>(prefix[3]) << 8) | prefix[4];
+        if (n <= (256u << 20)) s->rbuf.reserve(5 + n);
+      }
+      s->rbuf.append(reinterpret_cast<const char*>(data), len);
+    }
     const uint64_t call = MakeCall(index, c->id, stream);
     size_t off = 0;
     while (s->rbuf.size() - off >= 5) {
@@ -228,7 +240,15 @@ struct GrpcServerFront::Reactor {
         s = &it->second;
       } else {
         if (!end_stream || s->rbuf.size() - off - 5 != n) break;  // unary: wait for the whole request
-        std::string message(s->rbuf, off + 5, n);
+        std::string message;
+        if (off == 0) {
+          // take the receive buffer itself and drop the prefix in place: no second
+          // allocation (page faults included) and copy of a large request
+          message = std::move(s->rbuf);
+          message.erase(0, 5);
+        } else {
+          message.assign(s->rbuf, off + 5, n);
+        }
         s->rbuf.clear();
         off = 0;
         if (packed) {
