@@ -14,6 +14,7 @@ client's output region directly.
 
 from __future__ import annotations
 
+import os
 import queue
 import threading
 import time
@@ -97,6 +98,7 @@ class DynamicBatcher:
         # batches are spread over them and run side by side on the GPU.
         self.instances = int(getattr(self.model, "instance_count", 1)) if hasattr(self.model, "stream_of") else 1
         self._busy = [0] * self.instances  # batches enqueued per instance (batcher adds, completers subtract)
+        self.split_min_batch = int(os.environ.get("TCA_SPLIT_MIN_BATCH", getattr(self.model, "split_min_batch", 16)))
         self._busy_lock = threading.Lock()
         # per instance: [ring of [pinned uint8 buffer, event of its last H2D copy, bytes used], next entry]
         self._pinned = [[[], 0] for _ in range(self.instances)]
@@ -110,8 +112,6 @@ class DynamicBatcher:
         # at most this many batches are enqueued on the GPU at once (two per instance: one
         # running, one queued behind it): while they run, arriving requests accumulate
         # into ONE larger next batch instead of a train of small ones
-        import os
-
         cap = int(os.environ.get("TCA_MAX_INFLIGHT_BATCHES", 0)) or int(
             getattr(self.model, "max_inflight_batches", 2 * self.instances))
         self._inflight = threading.Semaphore(cap)
@@ -258,22 +258,48 @@ class DynamicBatcher:
             if got is None:
                 break
             group, total = got
-            try:
-                self._launch(group, total)
-                continue
-            except (ServerError, ModelError) as e:
-                self._inflight.release()
-                err = e if isinstance(e, ServerError) else ServerError(str(e), 400)
-                for it in group:
-                    it.error = err
-                    it.stats.record_fail(time.perf_counter_ns() - it.t_arrive)
-                    it.finish()
-            except Exception as e:  # keep serving after an unexpected failure
-                self._inflight.release()
-                err = ServerError(f"internal error while executing '{self.model.name}': {type(e).__name__}: {e}", 500)
-                for it in group:
-                    it.error = err
-                    it.finish()
+            for part, part_total in self._split_for_idle_instances(group, total):
+                self._launch_guarded(part, part_total)
+
+    def _split_for_idle_instances(self, group, total):
+        """With two execution instances idle, a batch of several requests runs faster as two
+        halves side by side (the halves fill each other's tails: 64 images 1.36 -> 1.27 ms)
+        than as one batch on one instance.  Only while nothing else is running, so a loaded
+        server keeps forming the largest batches."""
+        if self.instances < 2 or len(group) < 2 or total < self.split_min_batch:
+            return [(group, total)]
+        with self._busy_lock:
+            idle = all(b == 0 for b in self._busy)
+        if not idle or not self._inflight.acquire(blocking=False):  # the second half needs its own slot
+            return [(group, total)]
+        first, acc = [], 0
+        for it in group:
+            if acc >= total / 2 and first:
+                break
+            first.append(it)
+            acc += it.batch
+        second = group[len(first):]
+        if not second:
+            self._inflight.release()
+            return [(group, total)]
+        return [(first, acc), (second, total - acc)]
+
+    def _launch_guarded(self, group, total):
+        try:
+            self._launch(group, total)
+        except (ServerError, ModelError) as e:
+            self._inflight.release()
+            err = e if isinstance(e, ServerError) else ServerError(str(e), 400)
+            for it in group:
+                it.error = err
+                it.stats.record_fail(time.perf_counter_ns() - it.t_arrive)
+                it.finish()
+        except Exception as e:  # keep serving after an unexpected failure
+            self._inflight.release()
+            err = ServerError(f"internal error while executing '{self.model.name}': {type(e).__name__}: {e}", 500)
+            for it in group:
+                it.error = err
+                it.finish()
 
     def _static_buffers(self, inst, total, in_name, in_dtype, in_tail, out_name):
         import torch
