@@ -97,14 +97,22 @@ __device__ __forceinline__ void DmaToLds(__amdgpu_buffer_rsrc_t rsrc, unsigned v
                                            static_cast<int>(voffset), soffset, 0, 0);
 }
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds>
+// Second, back-to-back GEMM of the fused form (kFuse): the convolution's output tile never
+// leaves the CU - it is multiplied by a 1x1 convolution's weights straight from LDS.
+struct Pointwise2 {
+  const _Float16* w;     // [n][BN] : the 1x1 convolution that follows (its K is the first convolution's Cout)
+  const _Float16* bias;  // [n] or null
+  int n;                 // its output channels (multiple of 64)
+};
+
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false>
 __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias,
                                                           const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ Y, int M, int N, int K, int relu,
                                                           RowMap map, int tiles_n, int xcd_chunk, unsigned x_bytes,
                                                           int stages, int splits, float* __restrict__ partials,
-                                                          unsigned* __restrict__ arrivals) {
+                                                          unsigned* __restrict__ arrivals, Pointwise2 pw2) {
   constexpr int kW = 2 * kWN;                // wavefronts: 2 along m x kWN along n
   constexpr int kT = 64 * kW;                // threads
   constexpr int kAVecs = BM * 8 / kT;        // 16-byte vectors per thread and stage (activation tile)
@@ -432,6 +440,142 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
           acc[ni][mi][3] += __uint_as_float(static_cast<unsigned>(hi >> 32));
         }
     }
+  }
+
+  if constexpr (kFuse) {
+    // ---- fused 1x1 convolution: Y = act(relu(conv + bias) x W2^T + bias2 (+ residual)) ----
+    // The first result tile [BM pixels][BN channels] (BN = all of its channels: tiles_n == 1)
+    // goes to LDS in the operand layout of the K loop above - one [BM][64] swizzled slab per
+    // 64 channels - and serves as the activation operand of a second GEMM whose K is BN.
+    // Its weights arrive by the same DMA, 64 output channels at a time, double buffered;
+    // every 64-channel chunk runs the usual transposing epilogue.  The intermediate
+    // activation is never written to memory and never read back.
+    constexpr int kSlabs = BN / kBK;
+    constexpr int kBN2 = 64;
+    constexpr int kNI2 = kBN2 / (16 * kWN);
+    static_assert(kNI2 >= 1 && BN % kBK == 0, "wave layout too wide for the 64-channel chunks of the fused GEMM");
+    constexpr int kW2Vecs = kBN2 * 8 * kSlabs / kT;
+    static_assert(kW2Vecs >= 1, "fused GEMM: fewer weight vectors than threads");
+    constexpr int kCPitch2 = kBN2 + 8;
+    _Float16* ts = lds;                              // [kSlabs][BM][kBK]
+    _Float16* w2s = lds + BM * BN;                   // [2][kSlabs][kBN2][kBK]
+    _Float16* cs2 = w2s + 2 * kSlabs * kBN2 * kBK;   // [BM][kCPitch2]
+    const int N2 = pw2.n;
+    const __amdgpu_buffer_rsrc_t w2_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw2.w), 0, N2 * BN * 2, 0x00020000);
+    unsigned w2_off[kW2Vecs];
+#pragma unroll
+    for (int i = 0; i < kW2Vecs; ++i) {
+      const int v = (i * kW + wave) * 64 + lane;
+      const int slab = v >> 9;  // 512 vectors (64 rows x 8 chunks) per slab
+      const int row = (v & 511) >> 3;
+      const int chunk = (v & 7) ^ ((row >> 1) & 7);
+      w2_off[i] = static_cast<unsigned>((row * BN + slab * kBK + chunk * 8) * 2);
+    }
+    auto issue_w2 = [&](int chunk_index, int buf) {
+#pragma unroll
+      for (int i = 0; i < kW2Vecs; ++i)
+        DmaToLds(w2_rsrc, w2_off[i], chunk_index * kBN2 * BN * 2, w2s + buf * (kSlabs * kBN2 * kBK) + (i * kW + wave) * 512);
+    };
+    issue_w2(0, 0);
+    // first result (+bias, ReLU) -> operand slabs
+#pragma unroll
+    for (int ni = 0; ni < kNI; ++ni) {
+      const int n_local = wn * (BN / kWN) + ni * 16 + (lane >> 4) * 4;
+      float b[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) {
+        const half4 bv = *reinterpret_cast<const half4*>(bias + n_local);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(bv[r]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < kMI; ++mi) {
+        const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
+        half4 packed;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[ni][mi][r] + b[r];
+          packed[r] = static_cast<_Float16>(v > 0.f ? v : 0.f);
+        }
+        const int chunk = ((n_local & 63) >> 3) ^ ((m_local >> 1) & 7);
+        *reinterpret_cast<half4*>(ts + (n_local >> 6) * (BM * kBK) + m_local * kBK + chunk * 8 + (n_local & 7)) = packed;
+      }
+    }
+    const int w2f_off = (wn * (kBN2 / kWN) + frag_row) * kBK + frag_chunk * 8;
+    const int chunks = N2 / kBN2;
+    for (int c = 0; c < chunks; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // chunk c's weights (and, the first time, the operand slabs) are in LDS
+      if (c + 1 < chunks) issue_w2(c + 1, (c + 1) & 1);
+      const _Float16* wbuf = w2s + (c & 1) * (kSlabs * kBN2 * kBK);
+      float4v acc2[kNI2][kMI];
+#pragma unroll
+      for (int ni = 0; ni < kNI2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < kMI; ++mi) acc2[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl = 0; sl < kSlabs; ++sl) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const _Float16* xs = ts + sl * (BM * kBK) + (xf_off ^ (kk * 32));
+          const _Float16* ws = wbuf + sl * (kBN2 * kBK) + (w2f_off ^ (kk * 32));
+          half8 xf[kMI], wf[kNI2];
+#pragma unroll
+          for (int mi = 0; mi < kMI; ++mi) xf[mi] = *reinterpret_cast<const half8*>(xs + mi * 16 * kBK);
+#pragma unroll
+          for (int ni = 0; ni < kNI2; ++ni) wf[ni] = *reinterpret_cast<const half8*>(ws + ni * 16 * kBK);
+#pragma unroll
+          for (int ni = 0; ni < kNI2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < kMI; ++mi)
+              acc2[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc2[ni][mi], 0, 0, 0);
+        }
+      }
+      // chunk epilogue: +bias2 -> cs2 (transposed) -> residual, ReLU, coalesced 16-byte stores
+#pragma unroll
+      for (int ni = 0; ni < kNI2; ++ni) {
+        const int n_local = wn * (kBN2 / kWN) + ni * 16 + (lane >> 4) * 4;
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pw2.bias != nullptr) {
+          const half4 bv = *reinterpret_cast<const half4*>(pw2.bias + c * kBN2 + n_local);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(bv[r]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < kMI; ++mi) {
+          const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
+          half4 packed;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) packed[r] = static_cast<_Float16>(acc2[ni][mi][r] + b[r]);
+          *reinterpret_cast<half4*>(cs2 + m_local * kCPitch2 + n_local) = packed;
+        }
+      }
+      __syncthreads();
+      constexpr int kRowVecs2 = kBN2 / 8;
+      constexpr int kOutVecs2 = BM * kRowVecs2 / kT;
+#pragma unroll
+      for (int i = 0; i < kOutVecs2; ++i) {
+        const int v = tid + i * kT;
+        const int row = v / kRowVecs2;
+        const int cv = v - row * kRowVecs2;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        half8 val = *reinterpret_cast<const half8*>(cs2 + row * kCPitch2 + cv * 8);
+        const long long off = static_cast<long long>(m) * N2 + c * kBN2 + cv * 8;
+        if (residual != nullptr) {
+          const half8 res = *reinterpret_cast<const half8*>(residual + off);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) val[j] = static_cast<_Float16>(static_cast<float>(val[j]) + static_cast<float>(res[j]));
+        }
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) val[j] = val[j] > static_cast<_Float16>(0) ? val[j] : static_cast<_Float16>(0);
+        }
+        *reinterpret_cast<half8*>(Y + off) = val;
+      }
+      // the next iteration's barrier orders these cs2 reads before its cs2 writes
+    }
+    return;
   }
 
   // accumulator (+bias, fp32) -> LDS as fp16 [BM][kCPitch]; D^T layout: lane holds
@@ -766,10 +910,10 @@ struct SplitK {
   int arrival_slots;
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds>
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, const SplitK& sk,
-                  hipStream_t st) {
+                  hipStream_t st, const Pointwise2& pw2 = Pointwise2{nullptr, nullptr, 0}) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = N / BN;
   const int blocks = tiles_m * tiles_n;
@@ -800,16 +944,22 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (!kGlds) stages = 2;
   if (stages > ktiles) stages = ktiles;
   size_t lds_bytes = static_cast<size_t>(stages) * (BM + BN) * kBK * sizeof(_Float16);
-  const size_t c_bytes = static_cast<size_t>(BM) * (BN + 8) * sizeof(_Float16);
+  size_t c_bytes = static_cast<size_t>(BM) * (BN + 8) * sizeof(_Float16);
+  if (kFuse) {
+    if (tiles_n != 1 || splits != 1 || pw2.w == nullptr || pw2.n <= 0 || pw2.n % 64 != 0) return -2;
+    // operand slabs of the first result + two weight chunks + the 64-channel output tile
+    c_bytes = (static_cast<size_t>(BM) * BN + 2 * static_cast<size_t>(BN) * 64 + static_cast<size_t>(BM) * (64 + 8)) * sizeof(_Float16);
+  }
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
   if (lds_bytes > 64 * 1024) {
     // above the default dynamic-LDS limit: raise it once per kernel instantiation
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
   }
-  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st, x, w, bias,
-                     residual, y, M, N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages, splits, sk.partials, sk.arrivals);
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st, x, w,
+                     bias, residual, y, M, N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages, splits, sk.partials, sk.arrivals,
+                     pw2);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
 }
@@ -909,6 +1059,57 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
     default: return -3;
   }
 #undef TCA_DISPATCH
+}
+
+// y = act(conv1x1(relu(conv(x, w1) + bias1), w2) + bias2 (+ residual)) in ONE kernel: the middle
+// activation ([pixels][mid] fp16) stays in LDS.  x: [batch,in_h,in_w,cin], w1: [mid][ksize][ksize][cin]
+// (mid = 64 or 128: one tile holds all of its channels), w2: [cout][mid], residual / y: [batch,oh,ow,cout].
+int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, const void* w2, const void* bias2,
+                              const void* residual, void* y, int batch, int in_h, int in_w, int ksize, int stride, int pad,
+                              int cin, int mid, int cout, int relu, void* stream) {
+  if (!x || !w1 || !w2 || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || stride <= 0 || ksize <= 0 || pad < 0) return -1;
+  if (cin % kBK != 0 || (mid != 64 && mid != 128) || cout % 64 != 0 || cout <= 0) return -2;
+  if (ksize == 1 && pad == 0) return -2;  // the fused form is instantiated for spatial kernels
+  const int oh = (in_h + 2 * pad - ksize) / stride + 1;
+  const int ow = (in_w + 2 * pad - ksize) / stride + 1;
+  if (oh <= 0 || ow <= 0) return -2;
+  const long long m_ll = static_cast<long long>(batch) * oh * ow;
+  const long long k_ll = static_cast<long long>(ksize) * ksize * cin;
+  const long long x_bytes_ll = static_cast<long long>(batch) * in_h * in_w * cin * 2;
+  const long long lead_bytes = (static_cast<long long>(pad) * in_w + pad) * cin * 2;
+  if (m_ll > 0x7FFFFFFF || k_ll > 0x7FFFFFFF || m_ll * cout * 2 >= (1ll << 40)) return -2;
+  if (x_bytes_ll + lead_bytes >= 0x7FFFFFFFll || k_ll * mid * 2 >= 0x7FFFFFFFll || ksize * ksize > 32 ||
+      static_cast<long long>(cout) * mid * 2 >= 0x7FFFFFFFll)
+    return -2;
+  const int M = static_cast<int>(m_ll);
+  const int K = static_cast<int>(k_ll);
+  RowMap map;
+  map.identity = 0;
+  map.ohw = oh * ow;
+  map.ow = ow;
+  map.in_h = in_h;
+  map.in_w = in_w;
+  map.stride = stride;
+  map.pad = pad;
+  map.ksize = ksize;
+  map.cin = cin;
+  const SplitK sk{1, nullptr, 0, nullptr, 0};
+  const Pointwise2 pw2{static_cast<const _Float16*>(w2), static_cast<const _Float16*>(bias2), cout};
+  const long long blocks = (M + 127) / 128;
+  const long long per_cu_wanted = (blocks + 255) / 256;
+  const long long per_cu_with_3 = (160 * 1024) / (3 * (128 + mid) * kBK * 2);
+  const int stages = per_cu_wanted <= per_cu_with_3 ? 3 : 2;
+  auto st = static_cast<hipStream_t>(stream);
+  auto xp = static_cast<const _Float16*>(x);
+  auto wp = static_cast<const _Float16*>(w1);
+  auto bp = static_cast<const _Float16*>(bias1);
+  auto rp = static_cast<const _Float16*>(residual);
+  auto yp = static_cast<_Float16*>(y);
+  if (mid == 64)
+    return LaunchConvGemm<128, 64, 4, true, true, true>(xp, wp, bp, rp, yp, M, mid, K, relu, map, static_cast<unsigned>(x_bytes_ll),
+                                                        stages, sk, st, pw2);
+  return LaunchConvGemm<128, 128, 4, true, true, true>(xp, wp, bp, rp, yp, M, mid, K, relu, map, static_cast<unsigned>(x_bytes_ll),
+                                                       stages, sk, st, pw2);
 }
 
 int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,

@@ -422,6 +422,64 @@ def test_conv_split_k_exact_and_repeatable(torch, staging):
     torch.testing.assert_close(auto.float(), want, rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("shape", [
+    # batch, H, W, Cin, Mid, Cout, stride, residual
+    (2, 56, 56, 64, 64, 256, 1, True),
+    (3, 28, 28, 128, 128, 512, 1, True),
+    (2, 56, 56, 128, 128, 512, 2, False),
+    (1, 15, 13, 64, 64, 128, 2, True),      # odd sizes, M = 56: one partial tile
+    (5, 7, 9, 192, 128, 64, 1, False),      # Cin of three K steps per tap, a single output chunk
+])
+def test_conv3x3_pointwise_fused_matches_reference(torch, shape):
+    """3x3 convolution + bias + ReLU + 1x1 convolution + bias + residual + ReLU in one kernel
+    against the two-step fp32 computation (middle activation rounded to fp16, as the kernel
+    keeps it), and against the two separate kernels."""
+    from triton_client_amd.ops import conv
+
+    b, h, w, cin, mid, cout, stride, with_res = shape
+    gen = torch.Generator(device="cuda").manual_seed(cin + mid * 3 + cout * 7 + h)
+    x = _nhwc(torch.randn(b, cin, h, w, device="cuda", generator=gen).half())
+    w1 = _nhwc((torch.randn(mid, cin, 3, 3, device="cuda", generator=gen) / (9 * cin) ** 0.5).half())
+    b1 = torch.randn(mid, device="cuda", generator=gen).half()
+    w2 = (torch.randn(cout, mid, device="cuda", generator=gen) / mid ** 0.5).half()
+    b2 = torch.randn(cout, device="cuda", generator=gen).half()
+    t = torch.nn.functional.conv2d(x.float(), w1.float(), b1.float(), stride=stride, padding=1).clamp_min(0)
+    ref = torch.nn.functional.conv2d(t.half().float(), w2.float().reshape(cout, mid, 1, 1), b2.float())
+    res = _nhwc(torch.randn(tuple(ref.shape), device="cuda", generator=gen).half()) if with_res else None
+    if res is not None:
+        ref = ref + res.float()
+    ref = ref.clamp_min(0)
+    got = conv.conv2d_pointwise(x, w1, b1, w2, b2, res, relu=True, stride=stride, padding=1)
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got.float(), ref, rtol=4e-3, atol=4e-3)
+    two = conv.conv1x1(conv.conv2d(x, w1, b1, None, relu=True, stride=stride, padding=1), w2, b2, res, relu=True)
+    torch.testing.assert_close(got.float(), two.float(), rtol=2e-3, atol=2e-3)
+
+
+def test_conv3x3_pointwise_fused_exact_integers(torch):
+    """Small integers keep every intermediate exact in fp16: a wrong slab, swizzle or chunk
+    order in the second GEMM changes sums."""
+    from triton_client_amd.ops import conv
+
+    for mid, cout in ((64, 192), (128, 256)):
+        x = _nhwc(torch.randint(-1, 2, (2, 64, 9, 11), device="cuda").half())
+        w1 = torch.zeros(mid, 64, 3, 3, device="cuda")
+        w1[torch.rand(mid, 64, 3, 3, device="cuda") < 0.05] = 1.0
+        w1[3, 5, 0, 2] = -2.0
+        w1 = _nhwc(w1.half())
+        b1 = torch.randint(-2, 3, (mid,), device="cuda").half()
+        w2 = torch.zeros(cout, mid, device="cuda")
+        w2[torch.rand(cout, mid, device="cuda") < 0.1] = 1.0
+        w2[7, mid - 1] = -3.0
+        w2 = w2.half()
+        b2 = torch.randint(-2, 3, (cout,), device="cuda").half()
+        t = torch.nn.functional.conv2d(x.float(), w1.float(), b1.float(), padding=1).clamp_min(0)
+        ref = torch.nn.functional.conv2d(t, w2.float().reshape(cout, mid, 1, 1), b2.float())
+        assert t.abs().max() < 2048 and ref.abs().max() < 2048  # exactly representable
+        got = conv.conv2d_pointwise(x, w1, b1, w2, b2, None, relu=False, padding=1)
+        assert torch.equal(got.float(), ref), (mid, cout)
+
+
 def test_batched_copy_many_entries_and_alignments(torch):
     from triton_client_amd.ops.copy import batched_copy
 

@@ -190,6 +190,8 @@ class ResNet50(Model):
         # cross-queue dependencies of a forked HIP graph cost more than the overlap wins
         # (b8 0.590 vs 0.526 ms, b128 2.626 vs 2.614 ms); kept as an A/B switch.
         self.overlap_shortcut = os.environ.get("TCA_RESNET_OVERLAP", "0") != "0"
+        # 3x3 convolution + 1x1 expansion of a bottleneck block as one kernel (A/B switch)
+        self.fused_expansion = os.environ.get("TCA_RESNET_FUSED_EXPANSION", "1") != "0"
         # Execution instances: each has its own HIP stream and its own captured graphs
         # (with private activation pools), so the dynamic batcher keeps this many batches
         # running side by side.  The tail of one batch's layers (fewer workgroups than the
@@ -335,11 +337,29 @@ class ResNet50(Model):
                 with torch.cuda.stream(side):
                     identity = pointwise(y, down, None, False)
             t = pointwise(y, a, None, True)
-            t = spatial(t, mid)
             if down is not None and side is not None:
                 main.wait_stream(side)
-            y = pointwise(t, c, identity, True)
+            if self._fuse_expansion(t, mid, c):
+                # 3x3 convolution and the 1x1 expansion in one kernel: the 64-channel middle
+                # activation never leaves LDS
+                w4, bias, stride, pad = mid
+                y = conv.conv2d_pointwise(t, w4, bias, c[0], c[1], identity, relu=True, stride=stride, padding=pad)
+            else:
+                t = spatial(t, mid)
+                y = pointwise(t, c, identity, True)
         return y.mean(dim=(2, 3))
+
+    def _fuse_expansion(self, t, mid, c):
+        """Whether a block's 3x3 convolution and 1x1 expansion run as one kernel.  Measured on
+        MI355X (``tools/dev/fused_block_bench.py``): with 64 middle channels the fused kernel
+        wins from batch 16 up (batch 128: 175 -> 128 us per block, the layers sit on the
+        memory roofline and the fusion removes a write and a read of the middle activation);
+        with 128 middle channels its LDS footprint leaves one block per CU and it loses."""
+        if not self.fused_expansion:
+            return False
+        w4, _, stride, pad = mid
+        pixels = t.shape[0] * ((t.shape[2] + 2 * pad - w4.shape[2]) // stride + 1) * ((t.shape[3] + 2 * pad - w4.shape[3]) // stride + 1)
+        return w4.shape[0] == 64 and w4.shape[1] % 64 == 0 and c[2] == 1 and c[0].shape[0] % 64 == 0 and pixels >= 16 * 3136
 
     def _forward_into(self, x, out):
         torch = self._torch
