@@ -447,8 +447,10 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     // The first result tile [BM pixels][BN channels] (BN = all of its channels: tiles_n == 1)
     // goes to LDS in the operand layout of the K loop above - one [BM][64] swizzled slab per
     // 64 channels - and serves as the activation operand of a second GEMM whose K is BN.
-    // Its weights arrive by the same DMA, 64 output channels at a time, double buffered;
-    // every 64-channel chunk runs the usual transposing epilogue.  The intermediate
+    // Its weights arrive by the same DMA, 64 output channels at a time, into ONE buffer that
+    // is refilled while the previous chunk's epilogue stores run (a second buffer would push
+    // the 128-channel form past the LDS budget of two blocks per CU); every 64-channel chunk
+    // runs the usual transposing epilogue.  The intermediate
     // activation is never written to memory and never read back.
     constexpr int kSlabs = BN / kBK;
     constexpr int kBN2 = 64;
@@ -458,8 +460,8 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     static_assert(kW2Vecs >= 1, "fused GEMM: fewer weight vectors than threads");
     constexpr int kCPitch2 = kBN2 + 8;
     _Float16* ts = lds;                              // [kSlabs][BM][kBK]
-    _Float16* w2s = lds + BM * BN;                   // [2][kSlabs][kBN2][kBK]
-    _Float16* cs2 = w2s + 2 * kSlabs * kBN2 * kBK;   // [BM][kCPitch2]
+    _Float16* w2s = lds + BM * BN;                   // [kSlabs][kBN2][kBK]
+    _Float16* cs2 = w2s + kSlabs * kBN2 * kBK;       // [BM][kCPitch2]
     const int N2 = pw2.n;
     const __amdgpu_buffer_rsrc_t w2_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw2.w), 0, N2 * BN * 2, 0x00020000);
@@ -472,12 +474,12 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
       const int chunk = (v & 7) ^ ((row >> 1) & 7);
       w2_off[i] = static_cast<unsigned>((row * BN + slab * kBK + chunk * 8) * 2);
     }
-    auto issue_w2 = [&](int chunk_index, int buf) {
+    auto issue_w2 = [&](int chunk_index) {
 #pragma unroll
       for (int i = 0; i < kW2Vecs; ++i)
-        DmaToLds(w2_rsrc, w2_off[i], chunk_index * kBN2 * BN * 2, w2s + buf * (kSlabs * kBN2 * kBK) + (i * kW + wave) * 512);
+        DmaToLds(w2_rsrc, w2_off[i], chunk_index * kBN2 * BN * 2, w2s + (i * kW + wave) * 512);
     };
-    issue_w2(0, 0);
+    issue_w2(0);
     // first result (+bias, ReLU) -> operand slabs
 #pragma unroll
     for (int ni = 0; ni < kNI; ++ni) {
@@ -506,8 +508,21 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     for (int c = 0; c < chunks; ++c) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // chunk c's weights (and, the first time, the operand slabs) are in LDS
-      if (c + 1 < chunks) issue_w2(c + 1, (c + 1) & 1);
-      const _Float16* wbuf = w2s + (c & 1) * (kSlabs * kBN2 * kBK);
+      const _Float16* wbuf = w2s;
+      // this chunk's residual rows travel while its MFMAs run (rows past M: the last row, unused)
+      constexpr int kRowVecs2 = kBN2 / 8;
+      constexpr int kOutVecs2 = BM * kRowVecs2 / kT;
+      half8 res_ahead[kOutVecs2];
+      if (residual != nullptr) {
+#pragma unroll
+        for (int i = 0; i < kOutVecs2; ++i) {
+          const int v = tid + i * kT;
+          const int row = v / kRowVecs2;
+          const int cv = v - row * kRowVecs2;
+          const int m = m0 + row < M ? m0 + row : M - 1;
+          res_ahead[i] = *reinterpret_cast<const half8*>(residual + static_cast<long long>(m) * N2 + c * kBN2 + cv * 8);
+        }
+      }
       float4v acc2[kNI2][kMI];
 #pragma unroll
       for (int ni = 0; ni < kNI2; ++ni)
@@ -550,9 +565,8 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
           *reinterpret_cast<half4*>(cs2 + m_local * kCPitch2 + n_local) = packed;
         }
       }
-      __syncthreads();
-      constexpr int kRowVecs2 = kBN2 / 8;
-      constexpr int kOutVecs2 = BM * kRowVecs2 / kT;
+      __syncthreads();  // the output chunk is in cs2, and every wave is done reading the weight buffer
+      if (c + 1 < chunks) issue_w2(c + 1);  // lands while the stores below run
 #pragma unroll
       for (int i = 0; i < kOutVecs2; ++i) {
         const int v = tid + i * kT;
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         half8 val = *reinterpret_cast<const half8*>(cs2 + row * kCPitch2 + cv * 8);
         const long long off = static_cast<long long>(m) * N2 + c * kBN2 + cv * 8;
         if (residual != nullptr) {
-          const half8 res = *reinterpret_cast<const half8*>(residual + off);
+          const half8 res = res_ahead[i];
 #pragma unroll
           for (int j = 0; j < 8; ++j) val[j] = static_cast<_Float16>(static_cast<float>(val[j]) + static_cast<float>(res[j]));
         }
@@ -947,8 +961,8 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   size_t c_bytes = static_cast<size_t>(BM) * (BN + 8) * sizeof(_Float16);
   if (kFuse) {
     if (tiles_n != 1 || splits != 1 || pw2.w == nullptr || pw2.n <= 0 || pw2.n % 64 != 0) return -2;
-    // operand slabs of the first result + two weight chunks + the 64-channel output tile
-    c_bytes = (static_cast<size_t>(BM) * BN + 2 * static_cast<size_t>(BN) * 64 + static_cast<size_t>(BM) * (64 + 8)) * sizeof(_Float16);
+    // operand slabs of the first result + one weight chunk + the 64-channel output tile
+    c_bytes = (static_cast<size_t>(BM) * BN + static_cast<size_t>(BN) * 64 + static_cast<size_t>(BM) * (64 + 8)) * sizeof(_Float16);
   }
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
   if (lds_bytes > 64 * 1024) {

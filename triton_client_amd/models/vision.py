@@ -351,15 +351,20 @@ class ResNet50(Model):
 
     def _fuse_expansion(self, t, mid, c):
         """Whether a block's 3x3 convolution and 1x1 expansion run as one kernel.  Measured on
-        MI355X (``tools/dev/fused_block_bench.py``): with 64 middle channels the fused kernel
-        wins from batch 16 up (batch 128: 175 -> 128 us per block, the layers sit on the
-        memory roofline and the fusion removes a write and a read of the middle activation);
-        with 128 middle channels its LDS footprint leaves one block per CU and it loses."""
+        MI355X (``tools/dev/fused_block_bench.py``, us per block, two kernels -> fused): with 64
+        middle channels 44 -> 34 at batch 32 and 170 -> 118 at batch 128 (the layers sit on the
+        memory roofline and the fusion removes a write and a read of the middle activation),
+        a tie at batch 8; with 128 middle channels 31 -> 29 at batch 32, 107 -> 90 and 84 -> 74
+        at batch 128, slower below batch 32."""
         if not self.fused_expansion:
             return False
         w4, _, stride, pad = mid
         pixels = t.shape[0] * ((t.shape[2] + 2 * pad - w4.shape[2]) // stride + 1) * ((t.shape[3] + 2 * pad - w4.shape[3]) // stride + 1)
-        return w4.shape[0] == 64 and w4.shape[1] % 64 == 0 and c[2] == 1 and c[0].shape[0] % 64 == 0 and pixels >= 16 * 3136
+        if w4.shape[1] % 64 != 0 or c[2] != 1 or c[0].shape[0] % 64 != 0:
+            return False
+        if w4.shape[0] == 64:
+            return pixels >= 16 * 3136
+        return w4.shape[0] == 128 and pixels >= 32 * 784
 
     def _forward_into(self, x, out):
         torch = self._torch
