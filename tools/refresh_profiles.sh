@@ -13,6 +13,7 @@ step "forward time, own kernels vs library" && timeout -k 10 300 python3 tools/m
     timeout -k 10 300 python3 tools/model_bench.py --no-fused > "$SUM/resnet50_forward_library.txt" 2>&1 || exit 1
 step "per-layer convolution bench" && timeout -k 10 600 python3 tools/conv_bench.py > "$SUM/conv_layer_bench.txt" 2>&1 || exit 1
 step "split-K bench" && timeout -k 10 300 python3 tools/dev/splitk_bench.py > "$SUM/splitk_bench.txt" 2>&1 || exit 1
+step "fused block bench" && timeout -k 10 300 python3 tools/dev/fused_block_bench.py > "$SUM/fused_block_bench.txt" 2>&1 || exit 1
 step "conv counters" && bash tools/conv_pmc.sh > /dev/null 2>&1 || exit 1
 step "secondary configurations" && timeout -k 10 300 python3 tools/secondary_bench.py --gpu 0 --out "$SUM/secondary_bench.jsonl" > /dev/null 2>&1 || exit 1
 step "transport matrix" && timeout -k 10 300 python3 tools/dev/shm_mode_matrix.py 2>&1 | grep RESULT > "$SUM/shm_mode_matrix.txt" || exit 1
