@@ -205,3 +205,73 @@ def test_resnet50_zero_copy_vs_wire(hipshm, gpu_server):
             hipshm.destroy_shared_memory_region(hin)
             hipshm.destroy_shared_memory_region(hout)
             pre.close()
+
+
+def test_concurrent_clients_get_their_own_answers(hipshm, gpu_server):
+    """Many clients at once, every one with its own images, batch size and transport (wire
+    or hipshm): the dynamic batcher merges them into shared batches, spreads the batches
+    over the model's execution instances and scatters the rows back.  Every answer must be
+    the answer to that client's own images (checked against the same images sent alone)."""
+    import threading
+
+    import tritonclient.grpc as mod
+
+    rng = np.random.default_rng(3)
+    n_clients, rounds = 12, 6
+    batches = [1, 2, 3, 4, 5, 8, 8, 8, 6, 7, 8, 1]
+    inputs = [(rng.standard_normal((b, 3, 224, 224)) * (0.5 + 0.1 * i)).astype(np.float16) for i, b in enumerate(batches)]
+    expected = []
+    with mod.InferenceServerClient(gpu_server.grpc_url) as c:
+        for x in inputs:  # one at a time: no merging
+            t = mod.InferInput("input", list(x.shape), "FP16").set_data_from_numpy(x)
+            expected.append(c.infer("resnet50", [t]).as_numpy("output"))
+    # different images must give different logits, or the check below proves nothing
+    assert np.abs(expected[5][0] - expected[6][0]).max() > 0.05
+    errors = []
+    start = threading.Barrier(n_clients)
+
+    def client(i):
+        x, want = inputs[i], expected[i]
+        b = x.shape[0]
+        regions = []
+        try:
+            with mod.InferenceServerClient(gpu_server.grpc_url) as c:
+                t = mod.InferInput("input", list(x.shape), "FP16")
+                o = mod.InferRequestedOutput("output")
+                if i % 2 == 0:  # device shared memory in both directions
+                    hin = hipshm.create_shared_memory_region(f"cc_in_{i}", x.nbytes, 0)
+                    hout = hipshm.create_shared_memory_region(f"cc_out_{i}", b * 4000, 0)
+                    regions += [hin, hout]
+                    hipshm.set_shared_memory_region(hin, [x])
+                    c.register_cuda_shared_memory(f"cc_in_{i}", hipshm.get_raw_handle(hin), 0, x.nbytes)
+                    c.register_cuda_shared_memory(f"cc_out_{i}", hipshm.get_raw_handle(hout), 0, b * 4000)
+                    t.set_shared_memory(f"cc_in_{i}", x.nbytes)
+                    o.set_shared_memory(f"cc_out_{i}", b * 4000)
+                else:
+                    t.set_data_from_numpy(x)
+                start.wait(timeout=60)
+                for _ in range(rounds):
+                    r = c.infer("resnet50", [t], outputs=[o])
+                    got = hipshm.get_contents_as_numpy(regions[1], np.float32, [b, 1000]) if regions else r.as_numpy("output")
+                    if not np.allclose(got, want, rtol=2e-2, atol=2e-2):
+                        errors.append((i, float(np.abs(got - want).max())))
+                        return
+                if regions:
+                    c.unregister_cuda_shared_memory(f"cc_in_{i}")
+                    c.unregister_cuda_shared_memory(f"cc_out_{i}")
+        except Exception as e:  # noqa: BLE001 - reported through the list
+            errors.append((i, repr(e)))
+        finally:
+            for h in regions:
+                hipshm.destroy_shared_memory_region(h)
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(n_clients)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not errors, errors
+    with mod.InferenceServerClient(gpu_server.grpc_url) as c:
+        stats = c.get_inference_statistics("resnet50", as_json=True)["model_stats"][0]
+        # requests were merged: fewer executions than requests
+        assert int(stats["execution_count"]) < int(stats["inference_stats"]["success"]["count"])
