@@ -105,14 +105,22 @@ struct Pointwise2 {
   int n;                 // its output channels (multiple of 64)
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false>
+// Third GEMM of the fused form (kN3 > 0): the NEXT block's first 1x1 convolution, fed by the
+// finished output chunks while they are still on the CU.
+struct Pointwise3 {
+  const _Float16* w;     // [kN3][n of Pointwise2]
+  const _Float16* bias;  // [kN3] or null
+  _Float16* out;         // [M][kN3] = relu(y x w^T + bias)
+};
+
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0>
 __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias,
                                                           const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ Y, int M, int N, int K, int relu,
                                                           RowMap map, int tiles_n, int xcd_chunk, unsigned x_bytes,
                                                           int stages, int splits, float* __restrict__ partials,
-                                                          unsigned* __restrict__ arrivals, Pointwise2 pw2) {
+                                                          unsigned* __restrict__ arrivals, Pointwise2 pw2, Pointwise3 pw3) {
   constexpr int kW = 2 * kWN;                // wavefronts: 2 along m x kWN along n
   constexpr int kT = 64 * kW;                // threads
   constexpr int kAVecs = BM * 8 / kT;        // 16-byte vectors per thread and stage (activation tile)
@@ -462,9 +470,31 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     _Float16* ts = lds;                              // [kSlabs][BM][kBK]
     _Float16* w2s = lds + BM * BN;                   // [kSlabs][kBN2][kBK]
     _Float16* cs2 = w2s + kSlabs * kBN2 * kBK;       // [BM][kCPitch2]
+    _Float16* ys = cs2 + BM * kCPitch2;              // [BM][kBK]: a finished output chunk as an operand slab (kN3 > 0)
+    _Float16* w3s = ys + BM * kBK;                   // [kN3][kBK]
     const int N2 = pw2.n;
+    constexpr int kNI3 = kN3 > 0 ? kN3 / (16 * kWN) : 1;
+    constexpr int kW3Vecs = kN3 > 0 ? kN3 * 8 / kT : 1;
+    static_assert(kN3 == 0 || (kN3 % (16 * kWN) == 0 && kN3 * 8 % kT == 0), "third GEMM: channel count does not fit the wave layout");
+    unsigned w3_off[kW3Vecs];
+    float4v acc3[kNI3][kMI];
+    if constexpr (kN3 > 0) {
+#pragma unroll
+      for (int i = 0; i < kW3Vecs; ++i) {
+        const int v = (i * kW + wave) * 64 + lane;
+        const int row = v >> 3;
+        const int chunk = (v & 7) ^ ((row >> 1) & 7);
+        w3_off[i] = static_cast<unsigned>((row * N2 + chunk * 8) * 2);
+      }
+#pragma unroll
+      for (int ni = 0; ni < kNI3; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < kMI; ++mi) acc3[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
     const __amdgpu_buffer_rsrc_t w2_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw2.w), 0, N2 * BN * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(kN3 > 0 ? pw3.w : pw2.w), 0, (kN3 > 0 ? kN3 : kBN2) * N2 * 2, 0x00020000);
     unsigned w2_off[kW2Vecs];
 #pragma unroll
     for (int i = 0; i < kW2Vecs; ++i) {
@@ -509,6 +539,11 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // chunk c's weights (and, the first time, the operand slabs) are in LDS
       const _Float16* wbuf = w2s;
+      if constexpr (kN3 > 0) {
+        // K columns c*64.. of the next convolution's weights; consumed after this chunk's epilogue
+#pragma unroll
+        for (int i = 0; i < kW3Vecs; ++i) DmaToLds(w3_rsrc, w3_off[i], c * kBN2 * 2, w3s + (i * kW + wave) * 512);
+      }
       // this chunk's residual rows travel while its MFMAs run (rows past M: the last row, unused)
       constexpr int kRowVecs2 = kBN2 / 8;
       constexpr int kOutVecs2 = BM * kRowVecs2 / kT;
@@ -586,8 +621,70 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
           for (int j = 0; j < 8; ++j) val[j] = val[j] > static_cast<_Float16>(0) ? val[j] : static_cast<_Float16>(0);
         }
         *reinterpret_cast<half8*>(Y + off) = val;
+        if constexpr (kN3 > 0)  // the finished values also become an operand slab (rows past M: stale, their results are not stored)
+          *reinterpret_cast<half8*>(ys + row * kBK + ((cv ^ ((row >> 1) & 7)) * 8)) = val;
       }
-      // the next iteration's barrier orders these cs2 reads before its cs2 writes
+      if constexpr (kN3 > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's third-GEMM weights have landed
+        __syncthreads();                                  // ... for every wave, and the slab is complete
+        const int w3f_off = (wn * (kN3 / kWN) + frag_row) * kBK + frag_chunk * 8;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const _Float16* xs = ys + (xf_off ^ (kk * 32));
+          const _Float16* ws = w3s + (w3f_off ^ (kk * 32));
+          half8 xf[kMI], wf[kNI3];
+#pragma unroll
+          for (int mi = 0; mi < kMI; ++mi) xf[mi] = *reinterpret_cast<const half8*>(xs + mi * 16 * kBK);
+#pragma unroll
+          for (int ni = 0; ni < kNI3; ++ni) wf[ni] = *reinterpret_cast<const half8*>(ws + ni * 16 * kBK);
+#pragma unroll
+          for (int ni = 0; ni < kNI3; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < kMI; ++mi)
+              acc3[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc3[ni][mi], 0, 0, 0);
+        }
+      }
+      // the next iteration's barrier orders these cs2 / slab reads before its writes
+    }
+    if constexpr (kN3 > 0) {
+      // third result: +bias, ReLU -> transposed through LDS (everything above is idle now) -> coalesced stores
+      constexpr int kCPitch3 = kN3 + 8;
+      _Float16* cs3 = lds;
+      __syncthreads();
+#pragma unroll
+      for (int ni = 0; ni < kNI3; ++ni) {
+        const int n_local = wn * (kN3 / kWN) + ni * 16 + (lane >> 4) * 4;
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pw3.bias != nullptr) {
+          const half4 bv = *reinterpret_cast<const half4*>(pw3.bias + n_local);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(bv[r]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < kMI; ++mi) {
+          const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
+          half4 packed;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc3[ni][mi][r] + b[r];
+            packed[r] = static_cast<_Float16>(v > 0.f ? v : 0.f);
+          }
+          *reinterpret_cast<half4*>(cs3 + m_local * kCPitch3 + n_local) = packed;
+        }
+      }
+      __syncthreads();
+      constexpr int kRowVecs3 = kN3 / 8;
+      constexpr int kOutVecs3 = BM * kRowVecs3 / kT;
+#pragma unroll
+      for (int i = 0; i < kOutVecs3; ++i) {
+        const int v = tid + i * kT;
+        const int row = v / kRowVecs3;
+        const int cv = v - row * kRowVecs3;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        *reinterpret_cast<half8*>(pw3.out + static_cast<long long>(m) * kN3 + cv * 8) =
+            *reinterpret_cast<const half8*>(cs3 + row * kCPitch3 + cv * 8);
+      }
     }
     return;
   }
@@ -924,10 +1021,11 @@ struct SplitK {
   int arrival_slots;
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false>
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, const SplitK& sk,
-                  hipStream_t st, const Pointwise2& pw2 = Pointwise2{nullptr, nullptr, 0}) {
+                  hipStream_t st, const Pointwise2& pw2 = Pointwise2{nullptr, nullptr, 0},
+                  const Pointwise3& pw3 = Pointwise3{nullptr, nullptr, nullptr}) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = N / BN;
   const int blocks = tiles_m * tiles_n;
@@ -963,17 +1061,23 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
     if (tiles_n != 1 || splits != 1 || pw2.w == nullptr || pw2.n <= 0 || pw2.n % 64 != 0) return -2;
     // operand slabs of the first result + one weight chunk + the 64-channel output tile
     c_bytes = (static_cast<size_t>(BM) * BN + static_cast<size_t>(BN) * 64 + static_cast<size_t>(BM) * (64 + 8)) * sizeof(_Float16);
+    if (kN3 > 0) {
+      if (pw3.w == nullptr || pw3.out == nullptr) return -2;
+      c_bytes += (static_cast<size_t>(BM) * 64 + static_cast<size_t>(kN3) * 64) * sizeof(_Float16);  // output slab + its weights
+      const size_t c3 = static_cast<size_t>(BM) * (kN3 + 8) * sizeof(_Float16);
+      if (c3 > c_bytes) c_bytes = c3;
+    }
   }
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
   if (lds_bytes > 64 * 1024) {
     // above the default dynamic-LDS limit: raise it once per kernel instantiation
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
   }
-  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st, x, w,
-                     bias, residual, y, M, N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages, splits, sk.partials, sk.arrivals,
-                     pw2);
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st,
+                     x, w, bias, residual, y, M, N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages, splits, sk.partials,
+                     sk.arrivals, pw2, pw3);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -1000 - static_cast<int>(e);
 }
@@ -1078,9 +1182,13 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
 // y = act(conv1x1(relu(conv(x, w1) + bias1), w2) + bias2 (+ residual)) in ONE kernel: the middle
 // activation ([pixels][mid] fp16) stays in LDS.  x: [batch,in_h,in_w,cin], w1: [mid][ksize][ksize][cin]
 // (mid = 64 or 128: one tile holds all of its channels), w2: [cout][mid], residual / y: [batch,oh,ow,cout].
+// With w3 / out3 (mid = 64 only): also out3 = relu(conv1x1(y, w3) + bias3), the first convolution of
+// the NEXT block (w3: [n3][cout], n3 = 64 or 128; out3: [batch,oh,ow,n3]), fed from the output chunks
+// while they are still on the CU.
 int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, const void* w2, const void* bias2,
                               const void* residual, void* y, int batch, int in_h, int in_w, int ksize, int stride, int pad,
-                              int cin, int mid, int cout, int relu, void* stream) {
+                              int cin, int mid, int cout, int relu, const void* w3, const void* bias3, void* out3, int n3,
+                              void* stream) {
   if (!x || !w1 || !w2 || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || stride <= 0 || ksize <= 0 || pad < 0) return -1;
   if (cin % kBK != 0 || (mid != 64 && mid != 128) || cout % 64 != 0 || cout <= 0) return -2;
   if (ksize == 1 && pad == 0) return -2;  // the fused form is instantiated for spatial kernels
@@ -1119,6 +1227,16 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   auto bp = static_cast<const _Float16*>(bias1);
   auto rp = static_cast<const _Float16*>(residual);
   auto yp = static_cast<_Float16*>(y);
+  if (w3 != nullptr) {
+    if (mid != 64 || out3 == nullptr || !relu || (n3 != 64 && n3 != 128) || static_cast<long long>(cout) * n3 * 2 >= 0x7FFFFFFFll)
+      return -2;
+    const Pointwise3 pw3{static_cast<const _Float16*>(w3), static_cast<const _Float16*>(bias3), static_cast<_Float16*>(out3)};
+    if (n3 == 64)
+      return LaunchConvGemm<128, 64, 4, true, true, true, 64>(xp, wp, bp, rp, yp, M, mid, K, relu, map,
+                                                              static_cast<unsigned>(x_bytes_ll), stages, sk, st, pw2, pw3);
+    return LaunchConvGemm<128, 64, 4, true, true, true, 128>(xp, wp, bp, rp, yp, M, mid, K, relu, map,
+                                                             static_cast<unsigned>(x_bytes_ll), stages, sk, st, pw2, pw3);
+  }
   if (mid == 64)
     return LaunchConvGemm<128, 64, 4, true, true, true>(xp, wp, bp, rp, yp, M, mid, K, relu, map, static_cast<unsigned>(x_bytes_ll),
                                                         stages, sk, st, pw2);

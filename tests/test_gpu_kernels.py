@@ -456,6 +456,33 @@ def test_conv3x3_pointwise_fused_matches_reference(torch, shape):
     torch.testing.assert_close(got.float(), two.float(), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("n3", [64, 128])
+@pytest.mark.parametrize("shape", [(2, 56, 56, 256, 1), (1, 15, 13, 128, 2), (3, 9, 11, 64, 1)])
+def test_conv3x3_pointwise_next_conv_fused(torch, shape, n3):
+    """The fused block kernel with the next block's first 1x1 convolution attached: both
+    results against the separate kernels and an fp32 reference."""
+    from triton_client_amd.ops import conv
+
+    b, h, w, cout, stride = shape
+    gen = torch.Generator(device="cuda").manual_seed(cout + n3 + h)
+    x = _nhwc(torch.randn(b, 64, h, w, device="cuda", generator=gen).half())
+    w1 = _nhwc((torch.randn(64, 64, 3, 3, device="cuda", generator=gen) / 24.0).half())
+    b1 = torch.randn(64, device="cuda", generator=gen).half()
+    w2 = (torch.randn(cout, 64, device="cuda", generator=gen) / 8.0).half()
+    b2 = torch.randn(cout, device="cuda", generator=gen).half()
+    w3 = (torch.randn(n3, cout, device="cuda", generator=gen) / cout ** 0.5).half()
+    b3 = torch.randn(n3, device="cuda", generator=gen).half()
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = _nhwc(torch.randn(b, cout, oh, ow, device="cuda", generator=gen).half())
+    y_ref = conv.conv2d_pointwise(x, w1, b1, w2, b2, res, relu=True, stride=stride, padding=1)
+    t_ref = torch.nn.functional.conv2d(y_ref.float(), w3.float().reshape(n3, cout, 1, 1), b3.float()).clamp_min(0)
+    y, t = conv.conv2d_pointwise(x, w1, b1, w2, b2, res, relu=True, stride=stride, padding=1, next_weight=w3, next_bias=b3)
+    assert torch.equal(y, y_ref)
+    assert t.shape == t_ref.shape
+    torch.testing.assert_close(t.float(), t_ref, rtol=4e-3, atol=4e-3)
+    torch.testing.assert_close(t.float(), conv.conv1x1(y_ref, w3, b3, None, relu=True).float(), rtol=2e-3, atol=2e-3)
+
+
 def test_conv3x3_pointwise_fused_exact_integers(torch):
     """Small integers keep every intermediate exact in fp16: a wrong slab, swizzle or chunk
     order in the second GEMM changes sums."""

@@ -56,5 +56,21 @@ for batch in (8, 32, 128):
         def fused():
             conv.conv2d_pointwise(x, w1, b1, w2, b2, res, relu=True, stride=stride, padding=1, out=out)
 
-        print(f"batch {batch:3d} {h}x{w} {cin}->{mid}->{cout} s{stride}: two kernels {graph_time(two):7.2f} us, fused {graph_time(fused):7.2f} us",
-              flush=True)
+        line = (f"batch {batch:3d} {h}x{w} {cin}->{mid}->{cout} s{stride}: two kernels {graph_time(two):7.2f} us, "
+                f"fused {graph_time(fused):7.2f} us")
+        if mid == 64:
+            # with the next block's first 1x1 convolution (cout -> 64) attached, vs running it separately
+            w3 = (torch.randn(64, cout, device=dev) / cout ** 0.5).half()
+            b3 = torch.randn(64, device=dev).half()
+            t3 = nhwc(torch.empty(batch, 64, oh, ow, device=dev, dtype=torch.float16))
+
+            def fused_then_next():
+                fused()
+                conv.conv1x1(out, w3, b3, None, relu=True, out=t3)
+
+            def three():
+                conv.conv2d_pointwise(x, w1, b1, w2, b2, res, relu=True, stride=stride, padding=1, out=out,
+                                      next_weight=w3, next_bias=b3)
+
+            line += f" | + next 1x1: separate {graph_time(fused_then_next):7.2f} us, attached {graph_time(three):7.2f} us"
+        print(line, flush=True)

@@ -93,7 +93,8 @@ def install(lib):
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.tca_conv_pointwise_launch.restype = c_int
     lib.tca_conv_pointwise_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                              c_void_p, c_void_p, c_int, c_void_p]
     lib.tca_conv_gemm_splitk_launch.restype = c_int
     lib.tca_conv_gemm_splitk_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -182,7 +182,8 @@ def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0,
     return out
 
 
-def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=True, stride=1, padding=0, out=None):
+def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=True, stride=1, padding=0, out=None,
+                     next_weight=None, next_bias=None):
     """``act(conv1x1(relu(conv2d(x, weight) + bias), weight2) + bias2 (+ residual))`` in one
     kernel: a bottleneck block's 3x3 convolution and the 1x1 expansion that follows it.
     The middle activation stays in LDS as the second GEMM's operand - it is never written
@@ -192,6 +193,12 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     weight   fp16 ``[Mid, Cin, R, R]`` channels-last, Mid = 64 or 128 (one tile holds every
              middle channel), Cin a multiple of 64
     weight2  fp16 ``[Cout, Mid]`` contiguous, Cout a multiple of 64
+
+    With ``next_weight`` (fp16 ``[N3, Cout]``, N3 = 64 or 128; Mid must be 64, ``relu`` on) the
+    kernel also computes ``relu(conv1x1(result, next_weight) + next_bias)`` - the first
+    convolution of the NEXT bottleneck block - from the output chunks while they are still on
+    the CU, and the call returns ``(result, next_result)``: that convolution's separate pass
+    over the (memory-bound) block output disappears.
     """
     import torch
 
@@ -217,12 +224,26 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     for b, c in ((bias, mid), (bias2, cout)):
         if b is not None and (b.numel() != c or b.dtype != torch.float16 or not b.is_contiguous()):
             raise ValueError("biases must be contiguous fp16 vectors of the matching channel count")
+    out3 = None
+    n3 = 0
+    if next_weight is not None:
+        n3 = next_weight.shape[0]
+        if (next_weight.dtype != torch.float16 or next_weight.numel() != n3 * cout or not next_weight.is_contiguous()
+                or n3 not in (64, 128) or mid != 64 or not relu):
+            raise ValueError("next_weight must be a contiguous fp16 [64 | 128, Cout] matrix (Mid = 64, relu on)")
+        if next_bias is not None and (next_bias.numel() != n3 or next_bias.dtype != torch.float16
+                                      or not next_bias.is_contiguous()):
+            raise ValueError("next_bias must be a contiguous fp16 vector of N3 elements")
+        out3 = torch.empty((n, n3, oh, ow), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
     rc = lib().tca_conv_pointwise_launch(
         x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, weight2.data_ptr(),
         bias2.data_ptr() if bias2 is not None else None, residual.data_ptr() if residual is not None else None,
-        out.data_ptr(), n, h, w, int(r), int(stride), int(padding), cin, mid, cout, 1 if relu else 0, _stream())
+        out.data_ptr(), n, h, w, int(r), int(stride), int(padding), cin, mid, cout, 1 if relu else 0,
+        next_weight.data_ptr() if next_weight is not None else None,
+        next_bias.data_ptr() if next_bias is not None else None,
+        out3.data_ptr() if out3 is not None else None, n3, _stream())
     check(rc, "tca_conv_pointwise_launch")
-    return out
+    return out if next_weight is None else (out, out3)
 
 
 def bias_act_(y, bias, residual=None, relu=False):
