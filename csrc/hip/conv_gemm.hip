@@ -470,8 +470,9 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     _Float16* ts = lds;                              // [kSlabs][BM][kBK]
     _Float16* w2s = lds + BM * BN;                   // [kSlabs][kBN2][kBK]
     _Float16* cs2 = w2s + kSlabs * kBN2 * kBK;       // [BM][kCPitch2]
-    _Float16* ys = cs2 + BM * kCPitch2;              // [BM][kBK]: a finished output chunk as an operand slab (kN3 > 0)
-    _Float16* w3s = ys + BM * kBK;                   // [kN3][kBK]
+    _Float16* ys = cs2;                              // [BM][kBK]: a finished output chunk as an operand slab (kN3 > 0);
+                                                     // shares cs2's space (one barrier apart) to keep three blocks per CU
+    _Float16* w3s = cs2 + BM * kCPitch2;             // [kN3][kBK]
     const int N2 = pw2.n;
     constexpr int kNI3 = kN3 > 0 ? kN3 / (16 * kWN) : 1;
     constexpr int kW3Vecs = kN3 > 0 ? kN3 * 8 / kT : 1;
@@ -535,8 +536,20 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     }
     const int w2f_off = (wn * (kBN2 / kWN) + frag_row) * kBK + frag_chunk * 8;
     const int chunks = N2 / kBN2;
+    // Output stores go through a buffer descriptor: a row past M gets an out-of-range offset and its
+    // store is dropped, so every wave issues exactly kOutVecs2 store instructions per chunk, without
+    // branches, and the counted waits below can leave them in flight (vector memory operations
+    // complete in issue order) instead of stalling a chunk on the acknowledgement of the previous
+    // chunk's writes.
+    constexpr int kRowVecs2 = kBN2 / 8;
+    constexpr int kOutVecs2 = BM * kRowVecs2 / kT;
+    using uint4v = __attribute__((ext_vector_type(4))) unsigned;
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(Y, 0, static_cast<int>(static_cast<unsigned>(M) * N2 * 2u), 0x00020000);
     for (int c = 0; c < chunks; ++c) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // in flight, oldest first: chunk c's weights, then the previous chunk's kOutVecs2 output stores
+      if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOutVecs2) : "memory");
       __syncthreads();  // chunk c's weights (and, the first time, the operand slabs) are in LDS
       const _Float16* wbuf = w2s;
       if constexpr (kN3 > 0) {
@@ -545,8 +558,6 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         for (int i = 0; i < kW3Vecs; ++i) DmaToLds(w3_rsrc, w3_off[i], c * kBN2 * 2, w3s + (i * kW + wave) * 512);
       }
       // this chunk's residual rows travel while its MFMAs run (rows past M: the last row, unused)
-      constexpr int kRowVecs2 = kBN2 / 8;
-      constexpr int kOutVecs2 = BM * kRowVecs2 / kT;
       half8 res_ahead[kOutVecs2];
       if (residual != nullptr) {
 #pragma unroll
@@ -601,32 +612,38 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         }
       }
       __syncthreads();  // the output chunk is in cs2, and every wave is done reading the weight buffer
-      if (c + 1 < chunks) issue_w2(c + 1);  // lands while the stores below run
+      if (c + 1 < chunks) issue_w2(c + 1);  // lands while the rest of this chunk runs
+      half8 vals[kOutVecs2];
+      unsigned y_off[kOutVecs2];
 #pragma unroll
       for (int i = 0; i < kOutVecs2; ++i) {
         const int v = tid + i * kT;
         const int row = v / kRowVecs2;
         const int cv = v - row * kRowVecs2;
         const int m = m0 + row;
-        if (m >= M) continue;
         half8 val = *reinterpret_cast<const half8*>(cs2 + row * kCPitch2 + cv * 8);
-        const long long off = static_cast<long long>(m) * N2 + c * kBN2 + cv * 8;
-        if (residual != nullptr) {
-          const half8 res = res_ahead[i];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) val[j] = static_cast<_Float16>(static_cast<float>(val[j]) + static_cast<float>(res[j]));
-        }
+        if (residual != nullptr) val = val + res_ahead[i];  // packed fp16 adds: the same rounding as adding in fp32
         if (relu) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) val[j] = val[j] > static_cast<_Float16>(0) ? val[j] : static_cast<_Float16>(0);
         }
-        *reinterpret_cast<half8*>(Y + off) = val;
-        if constexpr (kN3 > 0)  // the finished values also become an operand slab (rows past M: stale, their results are not stored)
-          *reinterpret_cast<half8*>(ys + row * kBK + ((cv ^ ((row >> 1) & 7)) * 8)) = val;
+        vals[i] = val;
+        y_off[i] = m < M ? (static_cast<unsigned>(m) * N2 + c * kBN2 + cv * 8) * 2u : kOutOfRange;
       }
       if constexpr (kN3 > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's third-GEMM weights have landed
-        __syncthreads();                                  // ... for every wave, and the slab is complete
+        __syncthreads();  // every thread has taken its vectors out of cs2: its space becomes the operand slab
+#pragma unroll
+        for (int i = 0; i < kOutVecs2; ++i) {  // the finished values as an operand slab (rows past M: unused results)
+          const int v = tid + i * kT;
+          const int row = v / kRowVecs2;
+          const int cv = v - row * kRowVecs2;
+          *reinterpret_cast<half8*>(ys + row * kBK + ((cv ^ ((row >> 1) & 7)) * 8)) = vals[i];
+        }
+        // in flight, oldest first: this chunk's third-GEMM weights, the residual rows (consumed above),
+        // the next chunk's second-GEMM weights: let only the last stay in flight
+        if (c + 1 < chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2Vecs) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the weights have landed for every wave, and the slab is complete
         const int w3f_off = (wn * (kN3 / kWN) + frag_row) * kBK + frag_chunk * 8;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -644,6 +661,10 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
               acc3[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc3[ni][mi], 0, 0, 0);
         }
       }
+      // last in the chunk, so nothing in it waits for them
+#pragma unroll
+      for (int i = 0; i < kOutVecs2; ++i)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, vals[i]), y_rsrc, static_cast<int>(y_off[i]), 0, 0);
       // the next iteration's barrier orders these cs2 / slab reads before its writes
     }
     if constexpr (kN3 > 0) {
@@ -1063,7 +1084,7 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
     c_bytes = (static_cast<size_t>(BM) * BN + static_cast<size_t>(BN) * 64 + static_cast<size_t>(BM) * (64 + 8)) * sizeof(_Float16);
     if (kN3 > 0) {
       if (pw3.w == nullptr || pw3.out == nullptr) return -2;
-      c_bytes += (static_cast<size_t>(BM) * 64 + static_cast<size_t>(kN3) * 64) * sizeof(_Float16);  // output slab + its weights
+      c_bytes += static_cast<size_t>(kN3) * 64 * sizeof(_Float16);  // the third GEMM's weights (its operand slab shares cs2's space)
       const size_t c3 = static_cast<size_t>(BM) * (kN3 + 8) * sizeof(_Float16);
       if (c3 > c_bytes) c_bytes = c3;
     }
@@ -1199,7 +1220,7 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   const long long k_ll = static_cast<long long>(ksize) * ksize * cin;
   const long long x_bytes_ll = static_cast<long long>(batch) * in_h * in_w * cin * 2;
   const long long lead_bytes = (static_cast<long long>(pad) * in_w + pad) * cin * 2;
-  if (m_ll > 0x7FFFFFFF || k_ll > 0x7FFFFFFF || m_ll * cout * 2 >= (1ll << 40)) return -2;
+  if (m_ll > 0x7FFFFFFF || k_ll > 0x7FFFFFFF || m_ll * cout * 2 >= 0x7FFFFFFFll) return -2;  // output addressed by 32-bit byte offsets
   if (x_bytes_ll + lead_bytes >= 0x7FFFFFFFll || k_ll * mid * 2 >= 0x7FFFFFFFll || ksize * ksize > 32 ||
       static_cast<long long>(cout) * mid * 2 >= 0x7FFFFFFFll)
     return -2;
