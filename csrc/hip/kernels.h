@@ -80,6 +80,9 @@ int tca_conv1x1_launch(const void* x, const void* w, const void* bias, const voi
 int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                          int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu, int variant,
                          void* stream);
+int tca_avgpool_launch(const void* y, void* feats, int batch, int pixels, int channels, void* stream);
+int tca_linear_launch(const void* x, const void* w, const void* bias, void* out, int batch, int n_out, int k_total,
+                      void* stream);
 int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, const void* w2, const void* bias2,
                               const void* residual, void* y, int batch, int in_h, int in_w, int ksize, int stride, int pad,
                               int cin, int mid, int cout, int relu, const void* w3, const void* bias3, void* out3, int n3,

@@ -507,6 +507,26 @@ def test_conv3x3_pointwise_fused_exact_integers(torch):
         assert torch.equal(got.float(), ref), (mid, cout)
 
 
+@pytest.mark.parametrize("batch,n_out", [(1, 1000), (8, 1000), (37, 1000), (128, 1000), (5, 16), (16, 7)])
+def test_avgpool_linear_tail(torch, batch, n_out):
+    """Global average pooling + fully connected layer + bias with fp32 output against fp32
+    PyTorch (batches and class counts that are not multiples of the 16x16 MFMA tile included)."""
+    from triton_client_amd.ops import conv
+
+    gen = torch.Generator(device="cuda").manual_seed(batch * 31 + n_out)
+    y = _nhwc(torch.randn(batch, 2048, 7, 7, device="cuda", generator=gen).half())
+    w = (torch.randn(n_out, 2048, device="cuda", generator=gen) / 45.0).half()
+    b = torch.randn(n_out, device="cuda", generator=gen).half()
+    feats = y.float().mean(dim=(2, 3)).half().float()  # the kernel keeps the pooled features in fp16
+    ref = feats @ w.float().t() + b.float()
+    got = conv.avgpool_linear(y, w, b)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
+    out = torch.full((batch, n_out), float("nan"), device="cuda")
+    assert conv.avgpool_linear(y, w, None, out) is out
+    torch.testing.assert_close(out, ref - b.float(), rtol=2e-3, atol=2e-3)
+
+
 def test_batched_copy_many_entries_and_alignments(torch):
     from triton_client_amd.ops.copy import batched_copy
 

@@ -190,6 +190,8 @@ class ResNet50(Model):
         # cross-queue dependencies of a forked HIP graph cost more than the overlap wins
         # (b8 0.590 vs 0.526 ms, b128 2.626 vs 2.614 ms); kept as an A/B switch.
         self.overlap_shortcut = os.environ.get("TCA_RESNET_OVERLAP", "0") != "0"
+        # average pooling + fully connected layer on the in-tree kernels (A/B switch)
+        self.fused_tail = os.environ.get("TCA_RESNET_FUSED_TAIL", "1") != "0"
         # 3x3 convolution + 1x1 expansion of a bottleneck block as one kernel (A/B switch)
         self.fused_expansion = os.environ.get("TCA_RESNET_FUSED_EXPANSION", "1") != "0"
         # Execution instances: each has its own HIP stream and its own captured graphs
@@ -257,7 +259,7 @@ class ResNet50(Model):
     def _forward_eager(self, x):
         torch = self._torch
         if self.fused:
-            return self._net.fc(self._features_fused(x)).float()
+            return self._net.fc(self._features_fused(x).mean(dim=(2, 3))).float()
         return self._net(x.contiguous(memory_format=torch.channels_last)).float()
 
     def _build_plan(self):
@@ -356,7 +358,7 @@ class ResNet50(Model):
             else:
                 t = spatial(t, mid)
                 y = pointwise(t, c, identity, True)
-        return y.mean(dim=(2, 3))
+        return y
 
     def _attach_next(self, mid, c, nxt):
         """Whether the fused block kernel also computes the next block's first 1x1 convolution
@@ -389,7 +391,15 @@ class ResNet50(Model):
     def _forward_into(self, x, out):
         torch = self._torch
         if self.fused:
-            feats = self._features_fused(x)  # takes the client's NCHW layout as it is
+            y = self._features_fused(x)  # takes the client's NCHW layout as it is
+            if self.fused_tail:
+                # global average pooling + fully connected layer + bias, fp32 logits straight
+                # into `out` (two small kernels instead of reduction, GEMM and cast)
+                from ..ops import conv
+
+                conv.avgpool_linear(y, self._net.fc.weight, self._net.fc.bias, out)
+                return
+            feats = y.mean(dim=(2, 3))
         else:
             feats = self._net.features(x.contiguous(memory_format=torch.channels_last))
         logits = self._net.fc(feats)

@@ -91,6 +91,10 @@ def install(lib):
     lib.tca_conv_gemm_launch.restype = c_int
     lib.tca_conv_gemm_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.tca_avgpool_launch.restype = c_int
+    lib.tca_avgpool_launch.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.tca_linear_launch.restype = c_int
+    lib.tca_linear_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.tca_conv_pointwise_launch.restype = c_int
     lib.tca_conv_pointwise_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

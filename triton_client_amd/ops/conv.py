@@ -287,6 +287,34 @@ def bias_relu_maxpool(x, bias, out=None):
     return out
 
 
+def avgpool_linear(y, weight, bias=None, out=None):
+    """``linear(mean(y, dim=(2, 3)), weight, bias)`` as fp32: the classifier tail.  ``y`` is a
+    channels-last fp16 ``[N, C, H, W]`` tensor (C a multiple of 512), ``weight`` fp16 ``[Out, C]``
+    contiguous, ``out`` an optional fp32 ``[N, Out]`` contiguous destination (e.g. a view of a
+    client's shared-memory region)."""
+    import torch
+
+    if y.dtype != torch.float16 or not _is_nhwc(y):
+        raise ValueError("y must be a channels-last fp16 [N, C, H, W] tensor")
+    n, c, h, w = y.shape
+    n_out = weight.shape[0]
+    if weight.dtype != torch.float16 or weight.numel() != n_out * c or not weight.is_contiguous() or c % 512:
+        raise ValueError("weight must be a contiguous fp16 [Out, C] matrix with C a multiple of 512")
+    if bias is not None and (bias.numel() != n_out or bias.dtype != torch.float16 or not bias.is_contiguous()):
+        raise ValueError("bias must be a contiguous fp16 vector of Out elements")
+    if out is None:
+        out = torch.empty((n, n_out), dtype=torch.float32, device=y.device)
+    elif tuple(out.shape) != (n, n_out) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous fp32 [N, Out] tensor")
+    feats = torch.empty((n, c), dtype=torch.float16, device=y.device)
+    rc = lib().tca_avgpool_launch(y.data_ptr(), feats.data_ptr(), n, h * w, c, _stream())
+    check(rc, "tca_avgpool_launch")
+    rc = lib().tca_linear_launch(feats.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 out.data_ptr(), n, n_out, c, _stream())
+    check(rc, "tca_linear_launch")
+    return out
+
+
 def pack_stem_weight(weight):
     """``[64, 3, 7, 7]`` convolution weight -> the ``[64, 192]`` fp16 matrix the
     fused stem kernel reads: K ordered (c, kh, kw) with kw padded from 7 to 8 and
