@@ -40,6 +40,8 @@
 // ds_read_b128 of a fragment (16 rows x 4 chunks per wave instruction)
 // bank-conflict free for the instruction's four 16-lane groups.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 
 #include <cstdint>
@@ -1203,13 +1205,13 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
 // y = act(conv1x1(relu(conv(x, w1) + bias1), w2) + bias2 (+ residual)) in ONE kernel: the middle
 // activation ([pixels][mid] fp16) stays in LDS.  x: [batch,in_h,in_w,cin], w1: [mid][ksize][ksize][cin]
 // (mid = 64 or 128: one tile holds all of its channels), w2: [cout][mid], residual / y: [batch,oh,ow,cout].
-// With w3 / out3 (mid = 64 only): also out3 = relu(conv1x1(y, w3) + bias3), the first convolution of
+// tile_m: 0 (automatic), 64 or 128 pixels per tile.  With w3 / out3 (mid = 64 only): also out3 = relu(conv1x1(y, w3) + bias3), the first convolution of
 // the NEXT block (w3: [n3][cout], n3 = 64 or 128; out3: [batch,oh,ow,n3]), fed from the output chunks
 // while they are still on the CU.
 int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, const void* w2, const void* bias2,
                               const void* residual, void* y, int batch, int in_h, int in_w, int ksize, int stride, int pad,
                               int cin, int mid, int cout, int relu, const void* w3, const void* bias3, void* out3, int n3,
-                              void* stream) {
+                              int tile_m, void* stream) {
   if (!x || !w1 || !w2 || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || stride <= 0 || ksize <= 0 || pad < 0) return -1;
   if (cin % kBK != 0 || (mid != 64 && mid != 128) || cout % 64 != 0 || cout <= 0) return -2;
   if (ksize == 1 && pad == 0) return -2;  // the fused form is instantiated for spatial kernels
@@ -1238,9 +1240,13 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   map.cin = cin;
   const SplitK sk{1, nullptr, 0, nullptr, 0};
   const Pointwise2 pw2{static_cast<const _Float16*>(w2), static_cast<const _Float16*>(bias2), cout};
-  const long long blocks = (M + 127) / 128;
+  // tile_m: pixels per tile, 64 or 128; 0 = 64 while 128-pixel tiles would leave CUs without a block
+  if (tile_m != 0 && tile_m != 64 && tile_m != 128) return -2;
+  const long long blocks128 = (M + 127) / 128;
+  const int bm = tile_m ? tile_m : (blocks128 < 256 ? 64 : 128);
+  const long long blocks = (M + bm - 1) / bm;
   const long long per_cu_wanted = (blocks + 255) / 256;
-  const long long per_cu_with_3 = (160 * 1024) / (3 * (128 + mid) * kBK * 2);
+  const long long per_cu_with_3 = (160 * 1024) / (3 * (bm + mid) * kBK * 2);
   const int stages = per_cu_wanted <= per_cu_with_3 ? 3 : 2;
   auto st = static_cast<hipStream_t>(stream);
   auto xp = static_cast<const _Float16*>(x);
@@ -1248,21 +1254,24 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   auto bp = static_cast<const _Float16*>(bias1);
   auto rp = static_cast<const _Float16*>(residual);
   auto yp = static_cast<_Float16*>(y);
+  const unsigned xb = static_cast<unsigned>(x_bytes_ll);
+  Pointwise3 pw3{nullptr, nullptr, nullptr};
   if (w3 != nullptr) {
     if (mid != 64 || out3 == nullptr || !relu || (n3 != 64 && n3 != 128) || static_cast<long long>(cout) * n3 * 2 >= 0x7FFFFFFFll)
       return -2;
-    const Pointwise3 pw3{static_cast<const _Float16*>(w3), static_cast<const _Float16*>(bias3), static_cast<_Float16*>(out3)};
-    if (n3 == 64)
-      return LaunchConvGemm<128, 64, 4, true, true, true, 64>(xp, wp, bp, rp, yp, M, mid, K, relu, map,
-                                                              static_cast<unsigned>(x_bytes_ll), stages, sk, st, pw2, pw3);
-    return LaunchConvGemm<128, 64, 4, true, true, true, 128>(xp, wp, bp, rp, yp, M, mid, K, relu, map,
-                                                             static_cast<unsigned>(x_bytes_ll), stages, sk, st, pw2, pw3);
+    pw3 = Pointwise3{static_cast<const _Float16*>(w3), static_cast<const _Float16*>(bias3), static_cast<_Float16*>(out3)};
+  } else {
+    n3 = 0;
   }
-  if (mid == 64)
-    return LaunchConvGemm<128, 64, 4, true, true, true>(xp, wp, bp, rp, yp, M, mid, K, relu, map, static_cast<unsigned>(x_bytes_ll),
-                                                        stages, sk, st, pw2);
-  return LaunchConvGemm<128, 128, 4, true, true, true>(xp, wp, bp, rp, yp, M, mid, K, relu, map, static_cast<unsigned>(x_bytes_ll),
-                                                       stages, sk, st, pw2);
+#define TCA_FUSED(BM_, BN_, N3_) \
+  LaunchConvGemm<BM_, BN_, 4, true, true, true, N3_>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3)
+  if (bm == 64) {
+    if (mid == 128) return TCA_FUSED(64, 128, 0);
+    return n3 == 64 ? TCA_FUSED(64, 64, 64) : n3 == 128 ? TCA_FUSED(64, 64, 128) : TCA_FUSED(64, 64, 0);
+  }
+  if (mid == 128) return TCA_FUSED(128, 128, 0);
+  return n3 == 64 ? TCA_FUSED(128, 64, 64) : n3 == 128 ? TCA_FUSED(128, 64, 128) : TCA_FUSED(128, 64, 0);
+#undef TCA_FUSED
 }
 
 int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,

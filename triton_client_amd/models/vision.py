@@ -345,20 +345,36 @@ class ResNet50(Model):
                 main.wait_stream(side)
             nxt = blocks[index + 1][0] if index + 1 < len(blocks) else None
             attach = self._attach_next(mid, c, nxt)
-            if attach or self._fuse_expansion(t, mid, c):
+            w4, bias, stride, pad = mid
+            fuse, tile_m = attach or self._fuse_expansion(t, mid, c), 0
+            if self.fused_expansion and self._fusable(mid, c):
+                # what was measured for exactly this block and batch (tools/tune_conv.py) overrides the rules
+                mode = conv.tuned_block_mode(t.shape[2], t.shape[3], w4.shape[1], w4.shape[0], c[0].shape[0], stride,
+                                             nxt[0].shape[0] if attach else 0, t.shape[0])
+                if mode is not None:
+                    fuse, tile_m = mode != "none", int(mode) if mode != "none" else 0
+                    attach = attach and fuse
+            if fuse:
                 # 3x3 convolution and the 1x1 expansion in one kernel: the middle activation never
                 # leaves LDS; with `attach` the kernel also runs the next block's first 1x1
                 # convolution on the output chunks it has just produced
-                w4, bias, stride, pad = mid
                 if attach:
                     y, t_ahead = conv.conv2d_pointwise(t, w4, bias, c[0], c[1], identity, relu=True, stride=stride,
-                                                       padding=pad, next_weight=nxt[0], next_bias=nxt[1])
+                                                       padding=pad, next_weight=nxt[0], next_bias=nxt[1], tile_m=tile_m)
                 else:
-                    y = conv.conv2d_pointwise(t, w4, bias, c[0], c[1], identity, relu=True, stride=stride, padding=pad)
+                    y = conv.conv2d_pointwise(t, w4, bias, c[0], c[1], identity, relu=True, stride=stride, padding=pad,
+                                              tile_m=tile_m)
             else:
                 t = spatial(t, mid)
                 y = pointwise(t, c, identity, True)
         return y
+
+    @staticmethod
+    def _fusable(mid, c):
+        """Shapes the fused block kernel is instantiated for."""
+        w4 = mid[0]
+        return (w4.shape[0] in (64, 128) and w4.shape[1] % 64 == 0 and w4.shape[2] == 3 and c[2] == 1
+                and c[0].shape[0] % 64 == 0)
 
     def _attach_next(self, mid, c, nxt):
         """Whether the fused block kernel also computes the next block's first 1x1 convolution

@@ -80,6 +80,32 @@ def _splitk_workspace(device):
     return ws
 
 
+_tuning = None
+
+
+def tuning_table():
+    """The tuned dispatch table measured by ``tools/tune_conv.py`` on an MI355X
+    (``conv_tuning_gfx950.json`` next to this module; ``TCA_CONV_TUNING=0`` ignores it):
+    ``{"conv": {"k,stride,h,w,cin,cout,residual,batch": variant}, "fused": {...: "none|64|128"}}``."""
+    global _tuning
+    if _tuning is None:
+        import json
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning_gfx950.json")
+        table = {"conv": {}, "fused": {}}
+        if os.environ.get("TCA_CONV_TUNING", "1") != "0" and os.path.exists(path):
+            with open(path) as fh:
+                table = json.load(fh)
+        _tuning = table
+    return _tuning
+
+
+def tuned_block_mode(h, w, cin, mid, cout, stride, n3, batch):
+    """"none" | "64" | "128" for a bottleneck block's fused kernel, or None when not measured."""
+    return tuning_table()["fused"].get(f"{h},{w},{cin},{mid},{cout},{stride},{n3},{batch}")
+
+
 def _stream():
     import torch
 
@@ -92,8 +118,12 @@ def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
 
-def _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, cout, relu, variant, staging, split_k):
+def _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, cout, relu, variant, staging, split_k,
+            tuned=True):
     """``split_k``: None = automatic when enabled (``SPLIT_K``), 1 = off, n > 1 = exactly n."""
+    if tuned and variant in (0, "auto"):
+        # a measured winner for exactly this layer and batch beats the kernel's threshold rule
+        variant = tuning_table()["conv"].get(f"{r},{stride},{h},{w},{cin},{cout},{int(residual is not None)},{n}", 0)
     code = _variant_code(variant, staging)
     splits = (0 if SPLIT_K else 1) if split_k is None else int(split_k)
     if splits == 1:
@@ -111,7 +141,7 @@ def _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, co
 
 
 def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0, out=None, staging=None,
-            split_k=None):
+            split_k=None, tuned=True):
     """``act(conv1x1(x, weight) + bias (+ residual))``.
 
     x        fp16 ``[N, Cin, H, W]`` channels-last
@@ -141,12 +171,12 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1, variant=0
         raise ValueError("residual must match the output (fp16, channels-last)")
     if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
-    _launch(x, weight, bias, residual, out, n, h, w, 1, stride, 0, cin, cout, relu, variant, staging, split_k)
+    _launch(x, weight, bias, residual, out, n, h, w, 1, stride, 0, cin, cout, relu, variant, staging, split_k, tuned)
     return out
 
 
 def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0, variant=0, out=None,
-           staging=None, split_k=None):
+           staging=None, split_k=None, tuned=True):
     """``act(conv2d(x, weight) + bias (+ residual))`` as an implicit GEMM on the
     MFMA kernel (square kernels, e.g. 3x3 with padding 1).
 
@@ -178,12 +208,12 @@ def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0,
         raise ValueError("residual must match the output (fp16, channels-last)")
     if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
-    _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, cout, relu, variant, staging, split_k)
+    _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, cout, relu, variant, staging, split_k, tuned)
     return out
 
 
 def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=True, stride=1, padding=0, out=None,
-                     next_weight=None, next_bias=None):
+                     next_weight=None, next_bias=None, tile_m=0):
     """``act(conv1x1(relu(conv2d(x, weight) + bias), weight2) + bias2 (+ residual))`` in one
     kernel: a bottleneck block's 3x3 convolution and the 1x1 expansion that follows it.
     The middle activation stays in LDS as the second GEMM's operand - it is never written
@@ -198,7 +228,8 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     kernel also computes ``relu(conv1x1(result, next_weight) + next_bias)`` - the first
     convolution of the NEXT bottleneck block - from the output chunks while they are still on
     the CU, and the call returns ``(result, next_result)``: that convolution's separate pass
-    over the (memory-bound) block output disappears.
+    over the (memory-bound) block output disappears.  ``tile_m`` = 64 or 128 pins the pixels per
+    tile (0: the tuned table, then a rule on the number of tiles).
     """
     import torch
 
@@ -241,7 +272,7 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
         out.data_ptr(), n, h, w, int(r), int(stride), int(padding), cin, mid, cout, 1 if relu else 0,
         next_weight.data_ptr() if next_weight is not None else None,
         next_bias.data_ptr() if next_bias is not None else None,
-        out3.data_ptr() if out3 is not None else None, n3, _stream())
+        out3.data_ptr() if out3 is not None else None, n3, int(tile_m), _stream())
     check(rc, "tca_conv_pointwise_launch")
     return out if next_weight is None else (out, out3)
 
