@@ -175,6 +175,9 @@ class ResNet50(Model):
 
     def __init__(self):
         super().__init__()
+        if os.environ.get("TCA_RESNET_MAX_BATCH"):  # experiments with the batcher's largest merged batch
+            self.max_batch_size = int(os.environ["TCA_RESNET_MAX_BATCH"])
+            self.warmup_batches = tuple(range(8, self.max_batch_size + 1, 8))
         self._torch = None
         self._net = None
         self._graphs = _GraphCache()
