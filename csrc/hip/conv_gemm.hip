@@ -468,13 +468,14 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     static_assert(kNI2 >= 1 && BN % kBK == 0, "wave layout too wide for the 64-channel chunks of the fused GEMM");
     constexpr int kW2Vecs = kBN2 * 8 * kSlabs / kT;
     static_assert(kW2Vecs >= 1, "fused GEMM: fewer weight vectors than threads");
-    constexpr int kCPitch2 = kBN2 + 8;
     _Float16* ts = lds;                              // [kSlabs][BM][kBK]
     _Float16* w2s = lds + BM * BN;                   // [kSlabs][kBN2][kBK]
-    _Float16* cs2 = w2s + kSlabs * kBN2 * kBK;       // [BM][kCPitch2]
-    _Float16* ys = cs2;                              // [BM][kBK]: a finished output chunk as an operand slab (kN3 > 0);
-                                                     // shares cs2's space (one barrier apart) to keep three blocks per CU
-    _Float16* w3s = cs2 + BM * kCPitch2;             // [kN3][kBK]
+    // [BM][kBK] in the operand-slab layout (128-byte rows, 16-byte chunks XOR (row >> 1) & 7): the
+    // transposing tile of a chunk's epilogue and, once its owner threads have put the finished values
+    // back in place, the activation operand of the third GEMM - one buffer, no extra pass
+    _Float16* cs2 = w2s + kSlabs * kBN2 * kBK;
+    _Float16* ys = cs2;
+    _Float16* w3s = cs2 + BM * kBK;                  // [kN3][kBK]
     const int N2 = pw2.n;
     constexpr int kNI3 = kN3 > 0 ? kN3 / (16 * kWN) : 1;
     constexpr int kW3Vecs = kN3 > 0 ? kN3 * 8 / kT : 1;
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
           half4 packed;
 #pragma unroll
           for (int r = 0; r < 4; ++r) packed[r] = static_cast<_Float16>(acc2[ni][mi][r] + b[r]);
-          *reinterpret_cast<half4*>(cs2 + m_local * kCPitch2 + n_local) = packed;
+          *reinterpret_cast<half4*>(cs2 + m_local * kBK + ((((n_local >> 3) ^ ((m_local >> 1) & 7)) << 3) + (n_local & 7))) = packed;
         }
       }
       __syncthreads();  // the output chunk is in cs2, and every wave is done reading the weight buffer
@@ -623,7 +624,8 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         const int row = v / kRowVecs2;
         const int cv = v - row * kRowVecs2;
         const int m = m0 + row;
-        half8 val = *reinterpret_cast<const half8*>(cs2 + row * kCPitch2 + cv * 8);
+        _Float16* slot = cs2 + row * kBK + ((cv ^ ((row >> 1) & 7)) * 8);
+        half8 val = *reinterpret_cast<const half8*>(slot);
         if (residual != nullptr) val = val + res_ahead[i];  // packed fp16 adds: the same rounding as adding in fp32
         if (relu) {
 #pragma unroll
@@ -631,16 +633,9 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         }
         vals[i] = val;
         y_off[i] = m < M ? (static_cast<unsigned>(m) * N2 + c * kBN2 + cv * 8) * 2u : kOutOfRange;
+        if constexpr (kN3 > 0) *reinterpret_cast<half8*>(slot) = val;  // finished value back in its own slot (rows past M: unused)
       }
       if constexpr (kN3 > 0) {
-        __syncthreads();  // every thread has taken its vectors out of cs2: its space becomes the operand slab
-#pragma unroll
-        for (int i = 0; i < kOutVecs2; ++i) {  // the finished values as an operand slab (rows past M: unused results)
-          const int v = tid + i * kT;
-          const int row = v / kRowVecs2;
-          const int cv = v - row * kRowVecs2;
-          *reinterpret_cast<half8*>(ys + row * kBK + ((cv ^ ((row >> 1) & 7)) * 8)) = vals[i];
-        }
         // in flight, oldest first: this chunk's third-GEMM weights, the residual rows (consumed above),
         // the next chunk's second-GEMM weights: let only the last stay in flight
         if (c + 1 < chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2Vecs) : "memory");
@@ -1083,7 +1078,7 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (kFuse) {
     if (tiles_n != 1 || splits != 1 || pw2.w == nullptr || pw2.n <= 0 || pw2.n % 64 != 0) return -2;
     // operand slabs of the first result + one weight chunk + the 64-channel output tile
-    c_bytes = (static_cast<size_t>(BM) * BN + static_cast<size_t>(BN) * 64 + static_cast<size_t>(BM) * (64 + 8)) * sizeof(_Float16);
+    c_bytes = (static_cast<size_t>(BM) * BN + static_cast<size_t>(BN) * 64 + static_cast<size_t>(BM) * 64) * sizeof(_Float16);
     if (kN3 > 0) {
       if (pw3.w == nullptr || pw3.out == nullptr) return -2;
       c_bytes += static_cast<size_t>(kN3) * 64 * sizeof(_Float16);  // the third GEMM's weights (its operand slab shares cs2's space)
@@ -1205,7 +1200,7 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
 // y = act(conv1x1(relu(conv(x, w1) + bias1), w2) + bias2 (+ residual)) in ONE kernel: the middle
 // activation ([pixels][mid] fp16) stays in LDS.  x: [batch,in_h,in_w,cin], w1: [mid][ksize][ksize][cin]
 // (mid = 64 or 128: one tile holds all of its channels), w2: [cout][mid], residual / y: [batch,oh,ow,cout].
-// tile_m: 0 (automatic), 64 or 128 pixels per tile.  With w3 / out3 (mid = 64 only): also out3 = relu(conv1x1(y, w3) + bias3), the first convolution of
+// tile_m: 0 (automatic), 64 or 128 pixels per tile.  With w3 / out3 (n3 = 64 or 128; with mid = 128 only 128): also out3 = relu(conv1x1(y, w3) + bias3), the first convolution of
 // the NEXT block (w3: [n3][cout], n3 = 64 or 128; out3: [batch,oh,ow,n3]), fed from the output chunks
 // while they are still on the CU.
 int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, const void* w2, const void* bias2,
@@ -1257,7 +1252,8 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   const unsigned xb = static_cast<unsigned>(x_bytes_ll);
   Pointwise3 pw3{nullptr, nullptr, nullptr};
   if (w3 != nullptr) {
-    if (mid != 64 || out3 == nullptr || !relu || (n3 != 64 && n3 != 128) || static_cast<long long>(cout) * n3 * 2 >= 0x7FFFFFFFll)
+    if (out3 == nullptr || !relu || (n3 != 64 && n3 != 128) || (mid == 128 && n3 != 128) ||
+        static_cast<long long>(cout) * n3 * 2 >= 0x7FFFFFFFll)
       return -2;
     pw3 = Pointwise3{static_cast<const _Float16*>(w3), static_cast<const _Float16*>(bias3), static_cast<_Float16*>(out3)};
   } else {
@@ -1266,10 +1262,10 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
 #define TCA_FUSED(BM_, BN_, N3_) \
   LaunchConvGemm<BM_, BN_, 4, true, true, true, N3_>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3)
   if (bm == 64) {
-    if (mid == 128) return TCA_FUSED(64, 128, 0);
+    if (mid == 128) return n3 == 128 ? TCA_FUSED(64, 128, 128) : TCA_FUSED(64, 128, 0);
     return n3 == 64 ? TCA_FUSED(64, 64, 64) : n3 == 128 ? TCA_FUSED(64, 64, 128) : TCA_FUSED(64, 64, 0);
   }
-  if (mid == 128) return TCA_FUSED(128, 128, 0);
+  if (mid == 128) return n3 == 128 ? TCA_FUSED(128, 128, 128) : TCA_FUSED(128, 128, 0);
   return n3 == 64 ? TCA_FUSED(128, 64, 64) : n3 == 128 ? TCA_FUSED(128, 64, 128) : TCA_FUSED(128, 64, 0);
 #undef TCA_FUSED
 }

@@ -456,19 +456,19 @@ def test_conv3x3_pointwise_fused_matches_reference(torch, shape):
     torch.testing.assert_close(got.float(), two.float(), rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("n3", [64, 128])
-@pytest.mark.parametrize("shape", [(2, 56, 56, 256, 1), (1, 15, 13, 128, 2), (3, 9, 11, 64, 1)])
-def test_conv3x3_pointwise_next_conv_fused(torch, shape, n3):
+@pytest.mark.parametrize("mid,n3", [(64, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("shape", [(2, 56, 56, 256, 1), (1, 15, 13, 128, 2), (3, 9, 11, 64, 1), (44, 28, 28, 512, 1)])
+def test_conv3x3_pointwise_next_conv_fused(torch, shape, mid, n3):
     """The fused block kernel with the next block's first 1x1 convolution attached: both
     results against the separate kernels and an fp32 reference."""
     from triton_client_amd.ops import conv
 
     b, h, w, cout, stride = shape
-    gen = torch.Generator(device="cuda").manual_seed(cout + n3 + h)
+    gen = torch.Generator(device="cuda").manual_seed(cout + n3 + h + mid)
     x = _nhwc(torch.randn(b, 64, h, w, device="cuda", generator=gen).half())
-    w1 = _nhwc((torch.randn(64, 64, 3, 3, device="cuda", generator=gen) / 24.0).half())
-    b1 = torch.randn(64, device="cuda", generator=gen).half()
-    w2 = (torch.randn(cout, 64, device="cuda", generator=gen) / 8.0).half()
+    w1 = _nhwc((torch.randn(mid, 64, 3, 3, device="cuda", generator=gen) / 24.0).half())
+    b1 = torch.randn(mid, device="cuda", generator=gen).half()
+    w2 = (torch.randn(cout, mid, device="cuda", generator=gen) / mid ** 0.5).half()
     b2 = torch.randn(cout, device="cuda", generator=gen).half()
     w3 = (torch.randn(n3, cout, device="cuda", generator=gen) / cout ** 0.5).half()
     b3 = torch.randn(n3, device="cuda", generator=gen).half()

@@ -19,8 +19,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = ("128x128w8", "128x64", "64x64", "128x64w8", "64x64w8")
 # (H, W, Cin, Mid, Cout, stride, next 1x1 outputs or 0) of the blocks the fused kernel covers
-FUSED_BLOCKS = [(56, 56, 64, 64, 256, 1, 64), (56, 56, 64, 64, 256, 1, 128), (56, 56, 128, 128, 512, 2, 0),
-                (28, 28, 128, 128, 512, 1, 0)]
+FUSED_BLOCKS = [(56, 56, 64, 64, 256, 1, 64), (56, 56, 64, 64, 256, 1, 128), (56, 56, 128, 128, 512, 2, 128),
+                (28, 28, 128, 128, 512, 1, 128), (28, 28, 128, 128, 512, 1, 0)]
 
 
 def main():

@@ -381,14 +381,15 @@ class ResNet50(Model):
 
     def _attach_next(self, mid, c, nxt):
         """Whether the fused block kernel also computes the next block's first 1x1 convolution
-        (64 middle channels; that convolution has stride 1 and 64 or 128 outputs).  It then
+        (that convolution has stride 1 and 64 or 128 outputs; 128 with 128 middle channels).  It then
         never makes its own pass over the block output, the largest tensor of the stage:
         per transition 21 -> 17 us at batch 8, 47 -> 40 at batch 32, 171 -> 148 at batch 128."""
         if not self.fused_expansion or nxt is None:
             return False
         w4 = mid[0]
-        return (w4.shape[0] == 64 and w4.shape[1] % 64 == 0 and c[2] == 1 and c[0].shape[0] % 64 == 0
-                and nxt[2] == 1 and nxt[0].shape[0] in (64, 128) and nxt[0].shape[1] == c[0].shape[0])
+        n3 = nxt[0].shape[0]
+        return (self._fusable(mid, c) and nxt[2] == 1 and nxt[0].shape[1] == c[0].shape[0]
+                and (n3 in (64, 128) if w4.shape[0] == 64 else n3 == 128))
 
     def _fuse_expansion(self, t, mid, c):
         """Whether a block's 3x3 convolution and 1x1 expansion run as one kernel.  Measured on

@@ -224,7 +224,7 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
              middle channel), Cin a multiple of 64
     weight2  fp16 ``[Cout, Mid]`` contiguous, Cout a multiple of 64
 
-    With ``next_weight`` (fp16 ``[N3, Cout]``, N3 = 64 or 128; Mid must be 64, ``relu`` on) the
+    With ``next_weight`` (fp16 ``[N3, Cout]``, N3 = 64 or 128, with Mid = 128 only 128; ``relu`` on) the
     kernel also computes ``relu(conv1x1(result, next_weight) + next_bias)`` - the first
     convolution of the NEXT bottleneck block - from the output chunks while they are still on
     the CU, and the call returns ``(result, next_result)``: that convolution's separate pass
@@ -260,8 +260,8 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     if next_weight is not None:
         n3 = next_weight.shape[0]
         if (next_weight.dtype != torch.float16 or next_weight.numel() != n3 * cout or not next_weight.is_contiguous()
-                or n3 not in (64, 128) or mid != 64 or not relu):
-            raise ValueError("next_weight must be a contiguous fp16 [64 | 128, Cout] matrix (Mid = 64, relu on)")
+                or n3 not in (64, 128) or (mid == 128 and n3 != 128) or not relu):
+            raise ValueError("next_weight must be a contiguous fp16 [64 | 128, Cout] matrix (128 rows with Mid = 128; relu on)")
         if next_bias is not None and (next_bias.numel() != n3 or next_bias.dtype != torch.float16
                                       or not next_bias.is_contiguous()):
             raise ValueError("next_bias must be a contiguous fp16 vector of N3 elements")
