@@ -15,6 +15,9 @@
 //       --shape NAME:DATATYPE:d0,d1,...      wire tensors (zero filled)
 //       --shm-input NAME:DATATYPE:dims:REGION:BYTES[:OFFSET]   registered shm input
 //       --shm-output NAME:REGION:BYTES[:OFFSET]
+//       --streaming          gRPC: requests travel on one bidirectional stream per connection
+//                            (decoupled models: any number of responses per request; a request
+//                            is complete at its final response).  Reports responses/sec as well.
 //       -b batch (only scales the reported infer/sec)
 #include <algorithm>
 #include <atomic>
@@ -71,7 +74,7 @@ int main(int argc, char** argv) {
   std::string url = "localhost:8000", model, version, protocol = "http";
   int concurrency = 1, batch = 1, connections = 1;
   long long count = 0, warmup_count = 0;
-  bool wait_go = false;
+  bool wait_go = false, streaming = false;
   double duration = 5.0, warmup = 1.0;
   std::vector<std::string> shapes, shm_in, shm_out;
   std::string trace_path;
@@ -86,6 +89,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--wait-go")) wait_go = true;
     else if (!std::strcmp(argv[i], "--connections")) connections = std::max(1, std::atoi(next()));
     else if (!std::strcmp(argv[i], "--trace")) trace_path = next();
+    else if (!std::strcmp(argv[i], "--streaming")) streaming = true;
     else if (!std::strcmp(argv[i], "-c")) concurrency = std::atoi(next());
     else if (!std::strcmp(argv[i], "-b")) batch = std::atoi(next());
     else if (!std::strcmp(argv[i], "-d")) duration = std::atof(next());
@@ -99,6 +103,7 @@ int main(int argc, char** argv) {
   for (auto& ch : protocol) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
   const bool use_grpc = protocol == "grpc";
   if (!use_grpc && protocol != "http") { std::cerr << "-i must be http or grpc" << std::endl; return 2; }
+  if (streaming && !use_grpc) { std::cerr << "--streaming needs -i grpc" << std::endl; return 2; }
   std::unique_ptr<tc::InferenceServerHttpClient> client;
   std::vector<std::unique_ptr<tc::InferenceServerGrpcClient>> grpc_clients;
   tca::Error e;
@@ -198,43 +203,78 @@ int main(int argc, char** argv) {
   long long to_finish = 0;  // count phase: completions still owed
   int outstanding = 0;
   uint64_t last_done_ns = 0;
+  std::atomic<uint64_t> responses{0};  // streaming: non-empty responses of the measured phase
 
-  std::function<void(int)> issue = [&](int s) {
+  std::function<void(int)> issue;
+  // one request of slot `s` is complete (unary: its response; streaming: its final response)
+  auto complete = [&](int s, const tca::Error& status, uint64_t t1) {
+    bool again = false;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      --outstanding;
+      last_done_ns = t1;
+      if (!status.IsOk()) {
+        ++errors;
+        if (first_error.empty()) first_error = status.Message();
+      } else if (record) {
+        latencies.push_back(t1 - slots[s]->t0);
+      }
+      if (record && tracing) trace_rows.push_back({slots[s]->t0, t1 - slots[s]->t0, s, status.IsOk()});
+      if (open_ended) {
+        again = !stopping;
+      } else {
+        --to_finish;
+        if (to_issue > 0) {
+          --to_issue;
+          again = true;
+        }
+      }
+      if (again) ++outstanding;
+      if (!again && (outstanding == 0 || (!open_ended && to_finish <= 0))) cv.notify_all();
+    }
+    if (again) issue(s);  // re-submitted from the reactor thread: zero idle time per slot
+  };
+  if (streaming) {
+    // the stream callback sees every response of every slot on that connection: the request id
+    // names the slot, the final flag ends the request
+    for (auto& g : grpc_clients) {
+      e = g->StartStream([&](tc::InferResult* r) {
+        const uint64_t t1 = NowNs();
+        tca::Error status = r->RequestStatus();
+        std::string id;
+        bool is_final = true, is_null = false;
+        r->Id(&id);
+        r->IsFinalResponse(&is_final);
+        r->IsNullResponse(&is_null);
+        delete r;
+        if (status.IsOk() && !is_null && record) responses.fetch_add(1, std::memory_order_relaxed);
+        if (!status.IsOk() || is_final) {
+          const int s = id.empty() ? 0 : std::atoi(id.c_str());
+          if (s >= 0 && s < static_cast<int>(slots.size())) complete(s, status, t1);
+        }
+      }, /*enable_stats=*/false);
+      if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+    }
+  }
+  issue = [&](int s) {
     Slot* slot = slots[s].get();
     slot->t0 = NowNs();
-    auto on_done = [&, s](tc::InferResult* r) {
-      const uint64_t t1 = NowNs();
-      tca::Error status = r->RequestStatus();
-      delete r;
-      bool again = false;
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        --outstanding;
-        last_done_ns = t1;
-        if (!status.IsOk()) {
-          ++errors;
-          if (first_error.empty()) first_error = status.Message();
-        } else if (record) {
-          latencies.push_back(t1 - slots[s]->t0);
-        }
-        if (record && tracing) trace_rows.push_back({slots[s]->t0, t1 - slots[s]->t0, s, status.IsOk()});
-        if (open_ended) {
-          again = !stopping;
-        } else {
-          --to_finish;
-          if (to_issue > 0) {
-            --to_issue;
-            again = true;
-          }
-        }
-        if (again) ++outstanding;
-        if (!again && (outstanding == 0 || (!open_ended && to_finish <= 0))) cv.notify_all();
-      }
-      if (again) issue(s);  // re-submitted from the reactor thread: zero idle time per slot
-    };
-    tca::Error se = use_grpc ? grpc_clients[s % grpc_clients.size()]->AsyncInfer(on_done, options, slot->in_ptrs,
-                                                                                slot->out_ptrs)
-                             : client->AsyncInfer(on_done, options, slot->in_ptrs, slot->out_ptrs);
+    tca::Error se;
+    if (streaming) {
+      tc::InferOptions per_request = options;
+      per_request.request_id_ = std::to_string(s);
+      per_request.triton_enable_empty_final_response_ = true;
+      se = grpc_clients[s % grpc_clients.size()]->AsyncStreamInfer(per_request, slot->in_ptrs, slot->out_ptrs);
+    } else {
+      auto on_done = [&, s](tc::InferResult* r) {
+        const uint64_t t1 = NowNs();
+        tca::Error status = r->RequestStatus();
+        delete r;
+        complete(s, status, t1);
+      };
+      se = use_grpc ? grpc_clients[s % grpc_clients.size()]->AsyncInfer(on_done, options, slot->in_ptrs, slot->out_ptrs)
+                    : client->AsyncInfer(on_done, options, slot->in_ptrs, slot->out_ptrs);
+    }
     if (!se.IsOk()) {
       std::lock_guard<std::mutex> lk(mu);
       ++errors;
@@ -341,9 +381,10 @@ int main(int argc, char** argv) {
   std::printf(
       "{\"requests\": %zu, \"errors\": %llu, \"duration_s\": %.4f, \"requests_per_sec\": %.2f, \"infer_per_sec\": %.2f, "
       "\"avg_us\": %.1f, \"p50_us\": %.1f, \"p90_us\": %.1f, \"p95_us\": %.1f, \"p99_us\": %.1f, \"concurrency\": %d, "
-      "\"protocol\": \"%s\", \"first_error\": \"%s\"}\n",
+      "\"protocol\": \"%s\", \"streaming\": %s, \"responses_per_sec\": %.2f, \"first_error\": \"%s\"}\n",
       lat.size(), static_cast<unsigned long long>(errors.load()), secs, lat.size() / secs, lat.size() * batch / secs,
       lat.empty() ? 0.0 : sum / lat.size() / 1e3, pct(50), pct(90), pct(95), pct(99), concurrency,
-      protocol.c_str(), first_error.substr(0, 200).c_str());
+      protocol.c_str(), streaming ? "true" : "false", streaming ? responses.load() / secs : lat.size() / secs,
+      first_error.substr(0, 200).c_str());
   return 0;
 }

@@ -4,7 +4,7 @@
   simple_http_sysshm      `simple` (add/sub, INT32[1,16]) over HTTP with system shared memory
   simple_grpc_wire        the same model over gRPC with tensors on the wire
   string_grpc_hipshm      `simple_string` (BYTES tensors) over gRPC with HIP shared memory
-  decoupled_stream        `repeat_int32`: responses/sec of one bidirectional stream
+  decoupled_stream        `repeat_int32` (16 responses per request) over bidirectional streams: responses/sec
 """
 import argparse
 import json
@@ -49,30 +49,10 @@ def main():
         emit(f"string_grpc_{shm}shm", concurrency=16, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
              p99_us=rows[0]["p99_us"])
 
-        import tritonclient.grpc as g
-
-        got = queue.Queue()
-        with g.InferenceServerClient(srv.grpc_url) as c:
-            c.start_stream(callback=lambda result, error: got.put((result, error)))
-            n_req, per_req = 200, 16
-            values = np.arange(per_req, dtype=np.int32)
-            inputs = [g.InferInput("IN", [per_req], "INT32"), g.InferInput("DELAY", [per_req], "UINT32"),
-                      g.InferInput("WAIT", [1], "UINT32")]
-            inputs[0].set_data_from_numpy(values)
-            inputs[1].set_data_from_numpy(np.zeros(per_req, dtype=np.uint32))
-            inputs[2].set_data_from_numpy(np.zeros(1, dtype=np.uint32))
-            t0 = time.perf_counter()
-            for i in range(n_req):
-                c.async_stream_infer("repeat_int32", inputs, request_id=str(i))
-            received = 0
-            while received < n_req * per_req:
-                result, error = got.get(timeout=60)
-                if error is not None:
-                    raise SystemExit(f"stream error: {error}")
-                received += 1
-            dt = time.perf_counter() - t0
-            c.stop_stream()
-        emit("decoupled_stream", requests=n_req, responses=received, responses_per_sec=round(received / dt, 1))
+        rows = perf(["-m", "repeat_int32", "-u", srv.grpc_url, "-i", "grpc", "--native", "--streaming", "--shape", "IN:16",
+                     "--shape", "DELAY:16", "--shape", "WAIT:1", "--concurrency-range", "16"] + common)
+        emit("decoupled_stream", concurrency=16, responses_per_request=16, requests_per_sec=rows[0]["requests_per_sec"],
+             responses_per_sec=rows[0]["responses_per_sec"], p50_us=rows[0]["p50_us"], p99_us=rows[0]["p99_us"])
     if args.out:
         with open(args.out, "w") as fh:
             for line in lines:
