@@ -102,9 +102,12 @@ __device__ __forceinline__ void DmaToLds(__amdgpu_buffer_rsrc_t rsrc, unsigned v
 // Second, back-to-back GEMM of the fused form (kFuse): the convolution's output tile never
 // leaves the CU - it is multiplied by a 1x1 convolution's weights straight from LDS.
 struct Pointwise2 {
-  const _Float16* w;     // [n][BN] : the 1x1 convolution that follows (its K is the first convolution's Cout)
+  const _Float16* w;     // [n][BN (+ 64 with xd)] : the 1x1 convolution that follows (its K is the first convolution's Cout)
   const _Float16* bias;  // [n] or null
   int n;                 // its output channels (multiple of 64)
+  // kXS = 1: a second activation operand [M][64] (the block's INPUT) whose 64 channels extend the second
+  // GEMM's K - the projection shortcut computed in the same accumulator instead of being read as a residual
+  const _Float16* xd;
 };
 
 // Third GEMM of the fused form (kN3 > 0): the NEXT block's first 1x1 convolution, fed by the
@@ -115,7 +118,7 @@ struct Pointwise3 {
   _Float16* out;         // [M][kN3] = relu(y x w^T + bias)
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0>
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0>
 __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias,
                                                           const _Float16* __restrict__ residual,
@@ -462,14 +465,14 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     // the 128-channel form past the LDS budget of two blocks per CU); every 64-channel chunk
     // runs the usual transposing epilogue.  The intermediate
     // activation is never written to memory and never read back.
-    constexpr int kSlabs = BN / kBK;
+    constexpr int kSlabs = BN / kBK + kXS;  // K steps of the second GEMM: the first result's channels (+ the extra operand's)
     constexpr int kBN2 = 64;
     constexpr int kNI2 = kBN2 / (16 * kWN);
     static_assert(kNI2 >= 1 && BN % kBK == 0, "wave layout too wide for the 64-channel chunks of the fused GEMM");
     constexpr int kW2Vecs = kBN2 * 8 * kSlabs / kT;
     static_assert(kW2Vecs >= 1, "fused GEMM: fewer weight vectors than threads");
     _Float16* ts = lds;                              // [kSlabs][BM][kBK]
-    _Float16* w2s = lds + BM * BN;                   // [kSlabs][kBN2][kBK]
+    _Float16* w2s = lds + BM * kBK * kSlabs;         // [kSlabs][kBN2][kBK]
     // [BM][kBK] in the operand-slab layout (128-byte rows, 16-byte chunks XOR (row >> 1) & 7): the
     // transposing tile of a chunk's epilogue and, once its owner threads have put the finished values
     // back in place, the activation operand of the third GEMM - one buffer, no extra pass
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         for (int mi = 0; mi < kMI; ++mi) acc3[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
     }
     const __amdgpu_buffer_rsrc_t w2_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw2.w), 0, N2 * BN * 2, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw2.w), 0, N2 * (kSlabs * kBK) * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(kN3 > 0 ? pw3.w : pw2.w), 0, (kN3 > 0 ? kN3 : kBN2) * N2 * 2, 0x00020000);
     unsigned w2_off[kW2Vecs];
@@ -506,14 +509,28 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
       const int slab = v >> 9;  // 512 vectors (64 rows x 8 chunks) per slab
       const int row = (v & 511) >> 3;
       const int chunk = (v & 7) ^ ((row >> 1) & 7);
-      w2_off[i] = static_cast<unsigned>((row * BN + slab * kBK + chunk * 8) * 2);
+      w2_off[i] = static_cast<unsigned>((row * (kSlabs * kBK) + slab * kBK + chunk * 8) * 2);
     }
     auto issue_w2 = [&](int chunk_index) {
 #pragma unroll
       for (int i = 0; i < kW2Vecs; ++i)
-        DmaToLds(w2_rsrc, w2_off[i], chunk_index * kBN2 * BN * 2, w2s + (i * kW + wave) * 512);
+        DmaToLds(w2_rsrc, w2_off[i], chunk_index * kBN2 * (kSlabs * kBK) * 2, w2s + (i * kW + wave) * 512);
     };
     issue_w2(0);
+    if constexpr (kXS > 0) {
+      // the extra operand slab: rows m0.. of the block input, 64 channels, straight into the slab after the first result's
+      const __amdgpu_buffer_rsrc_t xd_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<_Float16*>(pw2.xd), 0, static_cast<int>(static_cast<unsigned>(M) * kBK * 2u), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < kAVecs; ++i) {
+        const int v = (i * kW + wave) * 64 + lane;
+        const int row = v >> 3;
+        const int chunk = (v & 7) ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        DmaToLds(xd_rsrc, m < M ? static_cast<unsigned>((m * kBK + chunk * 8) * 2) : kOutOfRange, 0,
+                 ts + (BN / kBK) * (BM * kBK) + (i * kW + wave) * 512);
+      }
+    }
     // first result (+bias, ReLU) -> operand slabs
 #pragma unroll
     for (int ni = 0; ni < kNI; ++ni) {
@@ -1039,10 +1056,10 @@ struct SplitK {
   int arrival_slots;
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0>
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, const SplitK& sk,
-                  hipStream_t st, const Pointwise2& pw2 = Pointwise2{nullptr, nullptr, 0},
+                  hipStream_t st, const Pointwise2& pw2 = Pointwise2{nullptr, nullptr, 0, nullptr},
                   const Pointwise3& pw3 = Pointwise3{nullptr, nullptr, nullptr}) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = N / BN;
@@ -1078,7 +1095,9 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (kFuse) {
     if (tiles_n != 1 || splits != 1 || pw2.w == nullptr || pw2.n <= 0 || pw2.n % 64 != 0) return -2;
     // operand slabs of the first result + one weight chunk + the 64-channel output tile
-    c_bytes = (static_cast<size_t>(BM) * BN + static_cast<size_t>(BN) * 64 + static_cast<size_t>(BM) * 64) * sizeof(_Float16);
+    if ((kXS > 0) != (pw2.xd != nullptr)) return -2;
+    constexpr size_t k2 = BN + 64 * kXS;  // K of the second GEMM
+    c_bytes = (static_cast<size_t>(BM) * k2 + k2 * 64 + static_cast<size_t>(BM) * 64) * sizeof(_Float16);
     if (kN3 > 0) {
       if (pw3.w == nullptr || pw3.out == nullptr) return -2;
       c_bytes += static_cast<size_t>(kN3) * 64 * sizeof(_Float16);  // the third GEMM's weights (its operand slab shares cs2's space)
@@ -1089,11 +1108,11 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
   if (lds_bytes > 64 * 1024) {
     // above the default dynamic-LDS limit: raise it once per kernel instantiation
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
   }
-  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st,
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st,
                      x, w, bias, residual, y, M, N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages, splits, sk.partials,
                      sk.arrivals, pw2, pw3);
   const hipError_t e = hipGetLastError();
@@ -1206,7 +1225,7 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
 int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, const void* w2, const void* bias2,
                               const void* residual, void* y, int batch, int in_h, int in_w, int ksize, int stride, int pad,
                               int cin, int mid, int cout, int relu, const void* w3, const void* bias3, void* out3, int n3,
-                              int tile_m, void* stream) {
+                              int tile_m, const void* xd, void* stream) {
   if (!x || !w1 || !w2 || !y || batch <= 0 || in_h <= 0 || in_w <= 0 || stride <= 0 || ksize <= 0 || pad < 0) return -1;
   if (cin % kBK != 0 || (mid != 64 && mid != 128) || cout % 64 != 0 || cout <= 0) return -2;
   if (ksize == 1 && pad == 0) return -2;  // the fused form is instantiated for spatial kernels
@@ -1234,7 +1253,13 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   map.ksize = ksize;
   map.cin = cin;
   const SplitK sk{1, nullptr, 0, nullptr, 0};
-  const Pointwise2 pw2{static_cast<const _Float16*>(w2), static_cast<const _Float16*>(bias2), cout};
+  // xd: the block input [pixels][64] for a projection shortcut inside the kernel (mid = 64, stride 1, no
+  // residual): w2 is then [cout][mid + 64] = [expansion | projection] and bias2 the sum of both biases
+  if (xd != nullptr && (mid != 64 || stride != 1 || residual != nullptr || (n3 != 0 && n3 != 64) ||
+                        (reinterpret_cast<uintptr_t>(xd) & 15)))
+    return -2;
+  const Pointwise2 pw2{static_cast<const _Float16*>(w2), static_cast<const _Float16*>(bias2), cout,
+                       static_cast<const _Float16*>(xd)};
   // tile_m: pixels per tile, 64 or 128; 0 = 64 while 128-pixel tiles would leave CUs without a block
   if (tile_m != 0 && tile_m != 64 && tile_m != 128) return -2;
   const long long blocks128 = (M + 127) / 128;
@@ -1261,6 +1286,12 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   }
 #define TCA_FUSED(BM_, BN_, N3_) \
   LaunchConvGemm<BM_, BN_, 4, true, true, true, N3_>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3)
+#define TCA_FUSED_XS(BM_, N3_) \
+  LaunchConvGemm<BM_, 64, 4, true, true, true, N3_, 1>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3)
+  if (xd != nullptr) {
+    if (bm == 64) return n3 == 64 ? TCA_FUSED_XS(64, 64) : TCA_FUSED_XS(64, 0);
+    return n3 == 64 ? TCA_FUSED_XS(128, 64) : TCA_FUSED_XS(128, 0);
+  }
   if (bm == 64) {
     if (mid == 128) return n3 == 128 ? TCA_FUSED(64, 128, 128) : TCA_FUSED(64, 128, 0);
     return n3 == 64 ? TCA_FUSED(64, 64, 64) : n3 == 128 ? TCA_FUSED(64, 64, 128) : TCA_FUSED(64, 64, 0);
@@ -1268,6 +1299,7 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   if (mid == 128) return n3 == 128 ? TCA_FUSED(128, 128, 128) : TCA_FUSED(128, 128, 0);
   return n3 == 64 ? TCA_FUSED(128, 64, 64) : n3 == 128 ? TCA_FUSED(128, 64, 128) : TCA_FUSED(128, 64, 0);
 #undef TCA_FUSED
+#undef TCA_FUSED_XS
 }
 
 int tca_conv_gemm_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,

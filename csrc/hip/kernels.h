@@ -86,7 +86,7 @@ int tca_linear_launch(const void* x, const void* w, const void* bias, void* out,
 int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, const void* w2, const void* bias2,
                               const void* residual, void* y, int batch, int in_h, int in_w, int ksize, int stride, int pad,
                               int cin, int mid, int cout, int relu, const void* w3, const void* bias3, void* out3, int n3,
-                              int tile_m, void* stream);
+                              int tile_m, const void* xd, void* stream);
 int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                                 int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu,
                                 int variant, int splits, void* partials, unsigned long long partial_bytes,

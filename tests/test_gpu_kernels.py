@@ -483,6 +483,39 @@ def test_conv3x3_pointwise_next_conv_fused(torch, shape, mid, n3):
     torch.testing.assert_close(t.float(), conv.conv1x1(y_ref, w3, b3, None, relu=True).float(), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("attach", [False, True])
+@pytest.mark.parametrize("shape", [(2, 56, 56, 256), (1, 15, 13, 128), (44, 28, 28, 256)])
+def test_conv3x3_pointwise_projection_in_kernel(torch, shape, attach):
+    """The projection shortcut as extra K of the second GEMM (block input as a second operand
+    slab, weights side by side) against the separate computation in fp32."""
+    from triton_client_amd.ops import conv
+
+    b, h, w, cout = shape
+    gen = torch.Generator(device="cuda").manual_seed(cout + h + int(attach))
+    x0 = _nhwc(torch.randn(b, 64, h, w, device="cuda", generator=gen).half())  # block input
+    t = _nhwc(torch.randn(b, 64, h, w, device="cuda", generator=gen).half())   # first 1x1's output
+    w1 = _nhwc((torch.randn(64, 64, 3, 3, device="cuda", generator=gen) / 24.0).half())
+    b1 = torch.randn(64, device="cuda", generator=gen).half()
+    w2 = (torch.randn(cout, 64, device="cuda", generator=gen) / 8.0).half()
+    b2 = torch.randn(cout, device="cuda", generator=gen).half()
+    wd = (torch.randn(cout, 64, device="cuda", generator=gen) / 8.0).half()
+    bd = torch.randn(cout, device="cuda", generator=gen).half()
+    w3 = (torch.randn(64, cout, device="cuda", generator=gen) / cout ** 0.5).half()
+    b3 = torch.randn(64, device="cuda", generator=gen).half()
+    mid = torch.nn.functional.conv2d(t.float(), w1.float(), b1.float(), padding=1).clamp_min(0).half().float()
+    ref = (torch.nn.functional.conv2d(mid, w2.float().reshape(cout, 64, 1, 1), b2.float())
+           + torch.nn.functional.conv2d(x0.float(), wd.float().reshape(cout, 64, 1, 1), bd.float())).clamp_min(0)
+    wcat = torch.cat([w2, wd], dim=1).contiguous()
+    bcat = (b2.float() + bd.float()).half()
+    got = conv.conv2d_pointwise(t, w1, b1, wcat, bcat, None, relu=True, padding=1, proj_input=x0,
+                                next_weight=w3 if attach else None, next_bias=b3 if attach else None)
+    if attach:
+        got, nxt = got
+        nref = torch.nn.functional.conv2d(got.float(), w3.float().reshape(64, cout, 1, 1), b3.float()).clamp_min(0)
+        torch.testing.assert_close(nxt.float(), nref, rtol=4e-3, atol=4e-3)
+    torch.testing.assert_close(got.float(), ref, rtol=5e-3, atol=5e-3)
+
+
 def test_conv3x3_pointwise_fused_exact_integers(torch):
     """Small integers keep every intermediate exact in fp16: a wrong slab, swizzle or chunk
     order in the second GEMM changes sums."""

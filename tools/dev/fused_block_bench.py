@@ -73,4 +73,21 @@ for batch in (8, 32, 128):
                                       next_weight=w3, next_bias=b3)
 
             line += f" | + next 1x1: separate {graph_time(fused_then_next):7.2f} us, attached {graph_time(three):7.2f} us"
+            if stride == 1 and cin == 64:
+                # first block of the stage: projection shortcut (64 -> cout on the block input) as its own
+                # kernel + residual, vs inside the kernel
+                x0 = nhwc(torch.randn(batch, 64, oh, ow, device=dev).half())
+                wd = (torch.randn(cout, 64, device=dev) / 8.0).half()
+                bd = torch.randn(cout, device=dev).half()
+                wcat = torch.cat([w2, wd], dim=1).contiguous()
+
+                def with_down_kernel():
+                    conv.conv1x1(x0, wd, bd, None, relu=False, out=res)
+                    three()
+
+                def in_kernel():
+                    conv.conv2d_pointwise(x, w1, b1, wcat, b2, None, relu=True, stride=1, padding=1, out=out,
+                                          next_weight=w3, next_bias=b3, proj_input=x0)
+
+                line += f" | projection: own kernel {graph_time(with_down_kernel):7.2f} us, in kernel {graph_time(in_kernel):7.2f} us"
         print(line, flush=True)

@@ -135,6 +135,10 @@ def _build_resnet50(torch, num_classes=1000):
     return ResNet50()
 
 
+def _is_channels_last(torch, t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
 class _GraphCache:
     """LRU of captured HIP graphs keyed by (batch, in_ptr, out_ptr)."""
 
@@ -281,8 +285,14 @@ class ResNet50(Model):
                     m.conv.stride[0], m.conv.padding[0])
 
         blocks = []
-        for blk in net.blocks:
+        self._proj = {}  # block index -> ([expansion | projection] weights, summed bias) for the in-kernel shortcut
+        for index, blk in enumerate(net.blocks):
             blocks.append((mat(blk.a), spatial(blk.b), mat(blk.c), mat(blk.down) if blk.down is not None else None))
+            a, mid, c, down = blocks[-1]
+            if (down is not None and down[2] == 1 and down[0].shape[1] == 64 and mid[0].shape[0] == 64 and mid[2] == 1
+                    and c[2] == 1):
+                self._proj[index] = (torch.cat([c[0], down[0]], dim=1).contiguous(),
+                                     (c[1].float() + down[1].float()).half().contiguous())
         self._plan = (spatial(net.stem), blocks)
         # the stem also as the packed matrix of the fused conv + bias + ReLU + max-pool kernel
         from ..ops import conv
@@ -331,7 +341,14 @@ class ResNet50(Model):
         side = self._side_stream if self.overlap_shortcut else None
         t_ahead = None  # the next block's first convolution, when the previous block's kernel already produced it
         for index, (a, mid, c, down) in enumerate(blocks):
-            if down is None:
+            nxt = blocks[index + 1][0] if index + 1 < len(blocks) else None
+            # projection shortcut inside the block kernel (first block of stage 1): the block input becomes a
+            # second operand of the expansion GEMM; no separate kernel, no residual written and read back
+            proj = self._proj.get(index) if (self.fused_expansion and y.shape[1] == 64 and _is_channels_last(torch, y)
+                                             ) else None
+            if proj is not None:
+                identity = None
+            elif down is None:
                 identity = y
             elif side is None:
                 identity = pointwise(y, down, None, False)
@@ -346,9 +363,15 @@ class ResNet50(Model):
             t_ahead = None
             if down is not None and side is not None:
                 main.wait_stream(side)
-            nxt = blocks[index + 1][0] if index + 1 < len(blocks) else None
             attach = self._attach_next(mid, c, nxt)
             w4, bias, stride, pad = mid
+            if proj is not None:
+                n3_ok = attach and nxt[0].shape[0] == 64
+                result = conv.conv2d_pointwise(t, w4, bias, proj[0], proj[1], None, relu=True, stride=1, padding=pad,
+                                               proj_input=y, next_weight=nxt[0] if n3_ok else None,
+                                               next_bias=nxt[1] if n3_ok else None)
+                y, t_ahead = result if n3_ok else (result, None)
+                continue
             fuse, tile_m = attach or self._fuse_expansion(t, mid, c), 0
             if self.fused_expansion and self._fusable(mid, c):
                 # what was measured for exactly this block and batch (tools/tune_conv.py) overrides the rules

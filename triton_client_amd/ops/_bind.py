@@ -98,7 +98,7 @@ def install(lib):
     lib.tca_conv_pointwise_launch.restype = c_int
     lib.tca_conv_pointwise_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                              c_void_p, c_void_p, c_int, c_int, c_void_p]
+                                              c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.tca_conv_gemm_splitk_launch.restype = c_int
     lib.tca_conv_gemm_splitk_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -213,7 +213,7 @@ def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0,
 
 
 def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=True, stride=1, padding=0, out=None,
-                     next_weight=None, next_bias=None, tile_m=0):
+                     next_weight=None, next_bias=None, tile_m=0, proj_input=None):
     """``act(conv1x1(relu(conv2d(x, weight) + bias), weight2) + bias2 (+ residual))`` in one
     kernel: a bottleneck block's 3x3 convolution and the 1x1 expansion that follows it.
     The middle activation stays in LDS as the second GEMM's operand - it is never written
@@ -230,6 +230,12 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     the CU, and the call returns ``(result, next_result)``: that convolution's separate pass
     over the (memory-bound) block output disappears.  ``tile_m`` = 64 or 128 pins the pixels per
     tile (0: the tuned table, then a rule on the number of tiles).
+
+    ``proj_input`` (Mid = 64, stride 1, no ``residual``; N3 = 64 if any): the block's INPUT, a
+    channels-last fp16 ``[N, 64, OH, OW]`` tensor.  ``weight2`` is then ``[Cout, Mid + 64]`` - the
+    expansion's and the projection shortcut's weights side by side - and ``bias2`` the sum of their
+    biases: the shortcut is accumulated in the same fp32 accumulator (the second GEMM simply gets a
+    longer K) instead of being computed by its own kernel, written, and read back as a residual.
     """
     import torch
 
@@ -242,8 +248,9 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     if wcin != cin or r != s or not weight.is_contiguous(memory_format=torch.channels_last):
         raise ValueError("weight must be a channels-last [Mid, Cin, R, R] tensor with Cin matching x")
     cout = weight2.shape[0]
-    if weight2.numel() != cout * mid or not weight2.is_contiguous():
-        raise ValueError(f"weight2 must be a contiguous [{cout}, {mid}] matrix")
+    k2 = mid + (64 if proj_input is not None else 0)
+    if weight2.numel() != cout * k2 or not weight2.is_contiguous():
+        raise ValueError(f"weight2 must be a contiguous [{cout}, {k2}] matrix")
     oh, ow = (h + 2 * padding - r) // stride + 1, (w + 2 * padding - r) // stride + 1
     if out is None:
         out = torch.empty((n, cout, oh, ow), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
@@ -255,6 +262,10 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     for b, c in ((bias, mid), (bias2, cout)):
         if b is not None and (b.numel() != c or b.dtype != torch.float16 or not b.is_contiguous()):
             raise ValueError("biases must be contiguous fp16 vectors of the matching channel count")
+    if proj_input is not None:
+        if (mid != 64 or stride != 1 or residual is not None or proj_input.dtype != torch.float16
+                or tuple(proj_input.shape) != (n, 64, oh, ow) or not _is_nhwc(proj_input)):
+            raise ValueError("proj_input needs Mid = 64, stride 1, no residual and a channels-last fp16 [N, 64, OH, OW] tensor")
     out3 = None
     n3 = 0
     if next_weight is not None:
@@ -272,7 +283,8 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
         out.data_ptr(), n, h, w, int(r), int(stride), int(padding), cin, mid, cout, 1 if relu else 0,
         next_weight.data_ptr() if next_weight is not None else None,
         next_bias.data_ptr() if next_bias is not None else None,
-        out3.data_ptr() if out3 is not None else None, n3, int(tile_m), _stream())
+        out3.data_ptr() if out3 is not None else None, n3, int(tile_m),
+        proj_input.data_ptr() if proj_input is not None else None, _stream())
     check(rc, "tca_conv_pointwise_launch")
     return out if next_weight is None else (out, out3)
 
