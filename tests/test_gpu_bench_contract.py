@@ -1,0 +1,51 @@
+"""bench.py prints the one JSON line its callers parse, single rank and under
+``torch.distributed.run`` (two ranks sharing the one GPU of a test box, over gloo: RCCL
+refuses two ranks on one device; with one GPU per rank the default backend is RCCL)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config"}
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(line, gpus, steps, warmup):
+    assert REQUIRED <= set(line)
+    assert line["n_gpus"] == gpus and line["steps"] == steps and line["warmup"] == warmup
+    assert line["unit"] == "infer/sec" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["dtype"] == "fp16" and line["config"]["model"] == "resnet50" and line["config"]["batch"] == 8
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    # value is the whole job: requests x batch over the timed wall clock
+    per_step = line["config"]["requests_per_step_per_gpu"] * 8 * gpus
+    assert line["value"] == pytest.approx(per_step / (line["ms_per_step"] / 1e3), rel=1e-3)
+    assert line["p50_latency_us"] <= line["p99_latency_us"]
+
+
+def test_single_rank_line():
+    cmd = [sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--requests-per-step", "64", "--concurrency", "16"]
+    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=110)
+    assert done.returncode == 0, done.stderr[-2000:]
+    _check(_json_line(done.stdout), 1, 3, 1)
+
+
+def test_two_ranks_print_one_aggregate_line():
+    env = dict(os.environ, TCA_BENCH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--requests-per-step", "64", "--concurrency", "16"]
+    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=115, env=env)
+    assert done.returncode == 0, done.stderr[-2000:]
+    _check(_json_line(done.stdout), 2, 3, 1)
