@@ -56,6 +56,40 @@ def test_graph_replay_equals_eager(model):
     np.testing.assert_allclose(out.cpu().numpy(), eager.cpu().numpy(), rtol=1e-2, atol=1e-2)
 
 
+def test_graphs_of_one_instance_share_their_activation_memory(model):
+    """Every (batch, input buffer, output buffer) gets its own captured graph (zero-copy requests
+    run straight out of the client's region), but the graphs of one execution instance replay one
+    after the other on one stream: their activations must come from one pool, so that capturing
+    for new buffers does not grow the footprint - and interleaved replays stay correct."""
+    import torch
+
+    xs = [torch.randn(8, 3, 224, 224, device="cuda", dtype=torch.float16) for _ in range(6)]
+    outs = [torch.empty(8, 1000, device="cuda", dtype=torch.float32) for _ in range(6)]
+    big_x = torch.randn(32, 3, 224, 224, device="cuda", dtype=torch.float16)
+    big_out = torch.empty(32, 1000, device="cuda", dtype=torch.float32)
+    model.run(big_x, big_out)  # the largest batch sizes the pool
+    model.run(xs[0], outs[0])
+    model.stream.synchronize()
+    before = torch.cuda.memory_reserved()
+    for x, out in zip(xs[1:], outs[1:]):
+        model.run(x, out)
+    model.stream.synchronize()
+    grown = torch.cuda.memory_reserved() - before
+    assert grown <= 8 << 20, f"five more batch-8 graphs reserved {grown >> 20} MiB"
+    # replay in another order than captured, the large graph in between
+    for i in (3, 0, 5):
+        model.run(xs[i], outs[i])
+        model.run(big_x, big_out)
+    model.stream.synchronize()
+    with torch.no_grad(), torch.cuda.stream(model.stream):
+        eager = [model._forward_eager(xs[i]) for i in (3, 0, 5)]
+        eager_big = model._forward_eager(big_x)
+    model.stream.synchronize()
+    for i, ref in zip((3, 0, 5), eager):
+        np.testing.assert_allclose(outs[i].cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(big_out.cpu().numpy(), eager_big.cpu().numpy(), rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.gpu
 def test_gpu_ensemble_matches_client_side_preprocessing():
     """Encoded images through ``preprocess_resnet50_ensemble`` (host decode, HIP

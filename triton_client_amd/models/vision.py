@@ -242,6 +242,7 @@ class ResNet50(Model):
         self._build_plan()
         self._streams = [torch.cuda.Stream(device=self._device) for _ in range(self.instance_count)]
         self._stream = self._streams[0]
+        self._graph_pools = [None] * self.instance_count
         self._side_stream = torch.cuda.Stream(device=self._device)
         _LOADED[self.name] = self
         # immediate mode + the shipped tuned databases; TCA_MIOPEN_TUNE=1 runs
@@ -258,6 +259,7 @@ class ResNet50(Model):
         if _LOADED.get(self.name) is self:
             del _LOADED[self.name]
         self._graphs = _GraphCache()
+        self._graph_pools = [None] * len(getattr(self, "_graph_pools", []))
         self._net = None
         if self._torch is not None:
             self._torch.cuda.empty_cache()
@@ -466,20 +468,28 @@ class ResNet50(Model):
         with self._lock:
             graph = self._graphs.get(key)
             if graph is None:
-                graph = self._capture(x, out, stream)
+                graph = self._capture(x, out, stream, instance)
                 self._graphs.put(key, graph)
             with torch.cuda.stream(stream), _trace.range(f"resnet50 graph replay b={batch}"):
                 graph[0].replay()
         return out
 
-    def _capture(self, x, out, stream):
+    def _capture(self, x, out, stream, instance=0):
+        """Capture one forward as a HIP graph.  All graphs of one execution instance allocate
+        their activations from ONE memory pool: they only ever replay on that instance's
+        stream, one after the other, and nothing inside the pool outlives a replay (the
+        logits go to ``out``), so the footprint of an instance is that of its largest
+        batch instead of the sum over every (batch, buffer) pair that was ever captured.
+        Instances never share a pool - their graphs do run concurrently."""
         torch = self._torch
         with torch.no_grad():
             with torch.cuda.stream(stream):
                 self._forward_into(x, out)  # warm-up for this shape
             stream.synchronize()
-            g = torch.cuda.CUDAGraph()  # private memory pool: instances never share activations
-            with torch.cuda.graph(g, stream=stream):
+            if self._graph_pools[instance] is None:
+                self._graph_pools[instance] = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pools[instance], stream=stream):
                 self._forward_into(x, out)
         return (g, x, out)  # keep the tensors (hence the IPC mappings) alive
 
