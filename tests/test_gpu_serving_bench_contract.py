@@ -9,7 +9,8 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+# generous limits: on a fresh machine the first `import torch` of a child process alone can take minutes
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(420)]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -36,7 +37,7 @@ def _check(line, gpus, steps, warmup):
 
 def test_single_rank_line():
     cmd = [sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--requests-per-step", "64", "--concurrency", "16"]
-    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=110)
+    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert done.returncode == 0, done.stderr[-2000:]
     _check(_json_line(done.stdout), 1, 3, 1)
 
@@ -46,6 +47,6 @@ def test_two_ranks_print_one_aggregate_line():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--requests-per-step", "64", "--concurrency", "16"]
-    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=115, env=env)
+    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
     assert done.returncode == 0, done.stderr[-2000:]
     _check(_json_line(done.stdout), 2, 3, 1)
