@@ -486,10 +486,13 @@ class ResNet50(Model):
             with torch.cuda.stream(stream):
                 self._forward_into(x, out)  # warm-up for this shape
             stream.synchronize()
-            if self._graph_pools[instance] is None:
-                self._graph_pools[instance] = torch.cuda.graph_pool_handle()
+            pool = None  # A/B switch: a private pool per graph
+            if os.environ.get("TCA_RESNET_SHARED_GRAPH_POOL", "1") != "0":
+                if self._graph_pools[instance] is None:
+                    self._graph_pools[instance] = torch.cuda.graph_pool_handle()
+                pool = self._graph_pools[instance]
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._graph_pools[instance], stream=stream):
+            with torch.cuda.graph(g, pool=pool, stream=stream):
                 self._forward_into(x, out)
         return (g, x, out)  # keep the tensors (hence the IPC mappings) alive
 
