@@ -233,10 +233,16 @@ class _HttpProtocol(asyncio.Protocol):
             lines.append(f"{k}: {v}")
         if close:
             lines.append("Connection: close")
-        self.transport.write(("\r\n".join(lines) + "\r\n\r\n").encode("latin-1"))
-        for p in parts:
-            if len(p):
-                self.transport.write(p)
+        head = ("\r\n".join(lines) + "\r\n\r\n").encode("latin-1")
+        if total <= 65536:
+            # one write = one send() and one segment train: a small response written as
+            # header + body costs two system calls and wakes the client twice
+            self.transport.write(b"".join([head, *parts]))
+        else:
+            self.transport.write(head)
+            for p in parts:
+                if len(p):
+                    self.transport.write(p)  # large tensors: no extra copy
         if close:
             self.transport.close()
             self.closing = True
