@@ -5,13 +5,18 @@ inputs and outputs in HIP shared memory (hipshm) and requests over gRPC.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches one rank per GPU through
-``python -m torch.distributed.run``; every rank starts the v2 server for its
-GPU (a child process: HIP IPC handles cannot be opened by their exporter),
-drives it with ``--concurrency`` outstanding requests and the ranks meet on
-RCCL barriers.  A *step* is ``--requests-per-step`` completed requests per GPU
-(each request = one batch of 8 images).  Rank 0 prints one JSON line; ``value``
-is the aggregate inferences/sec over all GPUs.
+One rank per GPU.  Under ``python -m torch.distributed.run`` (RANK / WORLD_SIZE
+in the environment) this process IS a rank; started plainly with ``--gpus N``
+(N > 1) it starts the N ranks itself as children (before touching the GPU),
+relays rank 0's JSON line and fails if any rank fails.  Every rank starts the
+v2 server for its GPU (a child process: HIP IPC handles cannot be opened by
+their exporter), drives it with ``--concurrency`` outstanding requests and the
+ranks meet on RCCL barriers.  A *step* is ``--requests-per-step`` completed
+requests per GPU (each request = one batch of 8 images).  Rank 0 prints one
+JSON line; ``value`` is the aggregate inferences/sec over all GPUs.  The line
+also carries short measurements of the same requests with the tensors on the
+wire and in system shared memory (``extra.wire`` / ``extra.system_shm``), so the
+shared-memory-versus-wire comparison comes from the same run.
 
 Data: synthetic images of the named shape, run through the HIP preprocessing
 kernel into the hipshm input regions before timing; weights: random-init
@@ -41,12 +46,15 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--concurrency", type=int, default=int(os.environ.get("TCA_BENCH_CONCURRENCY", "64")))
-    ap.add_argument("--requests-per-step", type=int, default=256,
+    ap.add_argument("--requests-per-step", type=int, default=1536,
                     help="requests per GPU that make up one timed step")
     ap.add_argument("--protocol", choices=["grpc", "http"], default="grpc")
     ap.add_argument("--shared-memory", choices=["hip", "system", "none"], default="hip")
     ap.add_argument("--model", default="resnet50")
-    ap.add_argument("--extra", action="store_true", help="also measure the wire path and the fan-out path")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short wire / system-shared-memory comparison runs")
+    ap.add_argument("--extra-requests", type=int, default=1536,
+                    help="requests per GPU of each comparison run (wire, system shm)")
     ap.add_argument("--client", choices=["native", "python"], default=os.environ.get("TCA_BENCH_CLIENT", "native"),
                     help="native: C++ load generator (tca_loadgen) over the in-tree gRPC/HTTP client; "
                          "python: tritonclient-API threads in this process")
@@ -62,12 +70,13 @@ if not os.path.exists(LOADGEN):
     LOADGEN = os.path.join(ROOT, "build", "bin", "tca_loadgen")
 
 
-def measure_native(args, url, device, dist, label):
-    """Closed loop driven by the C++ load generator.  This process only creates
-    the HIP shared-memory regions (filled by the HIP preprocessing kernel),
-    registers them and brackets the measured phase: the generator warms up,
-    prints READY, waits for the go line, then issues exactly steps x
-    requests-per-step requests with ``--concurrency`` outstanding."""
+def measure_native(args, url, device, dist, label, mode=None, steps=None, per_step=None, warmup_requests=None):
+    """Closed loop driven by the C++ load generator.  This process only prepares
+    the tensors (HIP preprocessing kernel -> HIP shared-memory regions, or system
+    shared memory, or nothing for tensors on the wire), registers the regions and
+    brackets the measured phase: the generator warms up, prints READY, waits for
+    the go line, then issues exactly steps x requests-per-step requests with
+    ``--concurrency`` outstanding."""
     import subprocess
 
     import numpy as np
@@ -75,12 +84,14 @@ def measure_native(args, url, device, dist, label):
 
     from triton_client_amd.ops.preprocess import Preprocessor
 
-    if args.shared_memory != "hip":
-        raise SystemExit("--client native drives the hip shared-memory configuration; use --client python otherwise")
+    mode = mode or args.shared_memory
+    steps = steps or args.steps
+    per_step = per_step or args.requests_per_step
+    if warmup_requests is None:
+        warmup_requests = max(1, args.warmup) * per_step
     if not os.path.exists(LOADGEN):
         raise SystemExit(f"{LOADGEN} is missing: run `python -m triton_client_amd._build cpp`")
     import tritonclient.grpc as grpcclient
-    import tritonclient.utils.cuda_shared_memory as hipshm
 
     b = args.batch
     in_bytes, out_bytes = b * 3 * 224 * 224 * 2, b * 1000 * 4
@@ -89,7 +100,7 @@ def measure_native(args, url, device, dist, label):
     pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=device)
     control = grpcclient.InferenceServerClient(url if args.protocol == "grpc" else args.control_url)
     regions = []
-    per_step = args.requests_per_step
+    cleanup = []
 
     def barrier():
         if dist is not None:
@@ -98,18 +109,46 @@ def measure_native(args, url, device, dist, label):
 
     proc = None
     try:
-        for i in range(args.concurrency):
-            hin = hipshm.create_shared_memory_region(f"in_{device}_{i}", in_bytes, device)
-            hout = hipshm.create_shared_memory_region(f"out_{device}_{i}", out_bytes, device)
-            regions += [hin, hout]
-            pre(images, hin)  # HIP kernel writes the batch straight into the region
-            control.register_cuda_shared_memory(f"in_{device}_{i}", hipshm.get_raw_handle(hin), device, in_bytes)
-            control.register_cuda_shared_memory(f"out_{device}_{i}", hipshm.get_raw_handle(hout), device, out_bytes)
         cmd = [LOADGEN, "-u", url, "-i", args.protocol, "-m", args.model, "-c", str(args.concurrency), "-b", str(b),
-               "--connections", str(args.connections), "--count", str(args.steps * per_step), "--warmup-count",
-               str(max(1, args.warmup) * per_step), "--wait-go",
-               "--shm-input", f"input:FP16:{b},3,224,224:in_{device}_{{slot}}:{in_bytes}",
-               "--shm-output", f"output:out_{device}_{{slot}}:{out_bytes}"]
+               "--connections", str(args.connections), "--count", str(steps * per_step), "--warmup-count",
+               str(warmup_requests), "--wait-go"]
+        if mode == "hip":
+            import tritonclient.utils.cuda_shared_memory as hipshm
+
+            for i in range(args.concurrency):
+                hin = hipshm.create_shared_memory_region(f"in_{device}_{i}", in_bytes, device)
+                hout = hipshm.create_shared_memory_region(f"out_{device}_{i}", out_bytes, device)
+                regions += [hin, hout]
+                pre(images, hin)  # HIP kernel writes the batch straight into the region
+                control.register_cuda_shared_memory(f"in_{device}_{i}", hipshm.get_raw_handle(hin), device, in_bytes)
+                control.register_cuda_shared_memory(f"out_{device}_{i}", hipshm.get_raw_handle(hout), device, out_bytes)
+                cleanup.append(lambda i=i: (control.unregister_cuda_shared_memory(f"in_{device}_{i}"),
+                                            control.unregister_cuda_shared_memory(f"out_{device}_{i}")))
+            destroy = hipshm.destroy_shared_memory_region
+        elif mode == "system":
+            import tritonclient.utils.shared_memory as sysshm
+
+            x = torch.empty(b, 3, 224, 224, device=f"cuda:{device}", dtype=torch.float16)
+            pre(images, x)
+            host = x.cpu().numpy()
+            for i in range(args.concurrency):
+                kin, kout = f"/tca_b_in_{os.getpid()}_{i}", f"/tca_b_out_{os.getpid()}_{i}"
+                hin = sysshm.create_shared_memory_region(f"in_{device}_{i}", kin, in_bytes)
+                hout = sysshm.create_shared_memory_region(f"out_{device}_{i}", kout, out_bytes)
+                regions += [hin, hout]
+                sysshm.set_shared_memory_region(hin, [host])
+                control.register_system_shared_memory(f"in_{device}_{i}", kin, in_bytes)
+                control.register_system_shared_memory(f"out_{device}_{i}", kout, out_bytes)
+                cleanup.append(lambda i=i: (control.unregister_system_shared_memory(f"in_{device}_{i}"),
+                                            control.unregister_system_shared_memory(f"out_{device}_{i}")))
+            destroy = sysshm.destroy_shared_memory_region
+        else:
+            destroy = None
+        if mode in ("hip", "system"):
+            cmd += ["--shm-input", f"input:FP16:{b},3,224,224:in_{device}_{{slot}}:{in_bytes}",
+                    "--shm-output", f"output:out_{device}_{{slot}}:{out_bytes}"]
+        else:
+            cmd += ["--shape", f"input:FP16:{b},3,224,224"]  # 1.2 MB of tensor bytes in every request
         proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
         ready = proc.stdout.readline().strip()
         if ready != "READY":
@@ -122,31 +161,37 @@ def measure_native(args, url, device, dist, label):
         barrier()
         elapsed = time.perf_counter() - t0
         proc.wait(timeout=30)
-        if result["errors"] or result["requests"] != args.steps * per_step:
+        if result["errors"] or result["requests"] != steps * per_step:
             raise RuntimeError(f"load generator reported {result['errors']} errors "
-                               f"({result['requests']} of {args.steps * per_step} requests): {result['first_error']}")
+                               f"({result['requests']} of {steps * per_step} requests): {result['first_error']}")
     finally:
         if proc is not None and proc.poll() is None:
             proc.kill()
-        for i in range(len(regions) // 2):
+        for fn in cleanup:
             try:
-                control.unregister_cuda_shared_memory(f"in_{device}_{i}")
-                control.unregister_cuda_shared_memory(f"out_{device}_{i}")
+                fn()
             except Exception:
                 pass
         for r in regions:
-            hipshm.destroy_shared_memory_region(r)
+            destroy(r)
         control.close()
         pre.close()
     pcts = [result["p50_us"], result["p90_us"], result["p95_us"], result["p99_us"]]
+    mine = steps * per_step * b / elapsed
+    per_gpu = [mine]
     if dist is not None:
         t = torch.tensor([elapsed] + pcts, device=args.reduce_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank bounds the job; percentiles: worst rank's
         elapsed, pcts = float(t[0].item()), [float(v) for v in t[1:].tolist()]
+        each = torch.zeros(dist.get_world_size(), device=args.reduce_device, dtype=torch.float64)
+        each[dist.get_rank()] = mine
+        dist.all_reduce(each)
+        per_gpu = [float(v) for v in each.tolist()]
     world = dist.get_world_size() if dist is not None else 1
-    return {"label": label, "infer_per_sec": world * args.steps * per_step * b / elapsed, "elapsed_s": elapsed,
+    return {"label": label, "infer_per_sec": world * steps * per_step * b / elapsed, "elapsed_s": elapsed,
             "p50_us": pcts[0], "p90_us": pcts[1], "p95_us": pcts[2], "p99_us": pcts[3],
-            "generator_infer_per_sec": result["infer_per_sec"]}
+            "generator_infer_per_sec": result["infer_per_sec"], "per_gpu_infer_per_sec": per_gpu,
+            "requests": world * steps * per_step}
 
 
 class Worker:
@@ -318,15 +363,49 @@ def measure(args, url, device, dist, label):
     }
 
 
+def launch_ranks(args):
+    """``--gpus N`` without a launcher: start the N ranks as children of this
+    process, which has not touched the GPU and only relays.  Rank 0's JSON line
+    goes to stdout; any rank failing fails the run."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in proc.stdout:
+        if line.startswith("{"):
+            lines.append(line.strip())
+        else:
+            sys.stderr.write(line)
+    code = proc.wait()
+    if code != 0:
+        raise SystemExit(code)
+    if len(lines) != 1:
+        raise SystemExit(f"expected one JSON line from rank 0, got {len(lines)}")
+    print(lines[0], flush=True)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): one rank per GPU is required")
     import torch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs at least one MI355X")
+    if args.dist_backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                         "(--dist-backend gloo rehearses several ranks on one GPU)")
     device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
     dist = None
@@ -352,13 +431,18 @@ def main():
         run = measure_native if args.client == "native" else measure
         main_result = run(args, url, device, dist, f"{args.protocol}+{args.shared_memory}shm")
         extras = {}
-        if args.extra:
-            for mode in ("none", "system"):
-                alt = argparse.Namespace(**vars(args))
-                alt.shared_memory = mode
-                alt.steps = max(2, args.steps // 4)
-                alt.warmup = 1
-                extras[mode] = measure(alt, url, device, dist, f"{args.protocol}+{mode}")
+        if not args.no_extras and args.client == "native":
+            # the same requests with the tensors inside the messages / in system shared memory:
+            # short runs, same server, same generator, same concurrency
+            for key, mode in (("wire", "none"), ("system_shm", "system")):
+                if mode == args.shared_memory:
+                    continue
+                r = measure_native(args, url, device, dist, f"{args.protocol}+{mode}", mode=mode, steps=1,
+                                   per_step=args.extra_requests, warmup_requests=max(64, args.extra_requests // 8))
+                extras[key] = {"infer_per_sec": round(r["infer_per_sec"], 2), "p50_latency_us": round(r["p50_us"], 1),
+                               "p99_latency_us": round(r["p99_us"], 1), "requests": r["requests"],
+                               "elapsed_s": round(r["elapsed_s"], 4)}
+                extras[key]["main_over_this"] = round(main_result["infer_per_sec"] / r["infer_per_sec"], 3)
     finally:
         server.stop()
     if dist is not None:
@@ -383,6 +467,9 @@ def main():
             "p90_latency_us": round(main_result["p90_us"], 1),
             "p95_latency_us": round(main_result["p95_us"], 1),
             "p99_latency_us": round(main_result["p99_us"], 1),
+            "ranks": n,
+            "rank_backend": ("rccl" if args.dist_backend == "nccl" else "gloo") if n > 1 else None,
+            "per_gpu_infer_per_sec": [round(v, 1) for v in main_result.get("per_gpu_infer_per_sec", [])],
             "config": {
                 "model": "resnet50",
                 "batch": args.batch,
@@ -398,8 +485,7 @@ def main():
             },
         }
         if extras:
-            line["extra"] = {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()}
-                             for k, v in extras.items()}
+            line["extra"] = extras
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

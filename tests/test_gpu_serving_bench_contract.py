@@ -33,10 +33,16 @@ def _check(line, gpus, steps, warmup):
     per_step = line["config"]["requests_per_step_per_gpu"] * 8 * gpus
     assert line["value"] == pytest.approx(per_step / (line["ms_per_step"] / 1e3), rel=1e-3)
     assert line["p50_latency_us"] <= line["p99_latency_us"]
+    assert line["ranks"] == gpus and len(line["per_gpu_infer_per_sec"]) == gpus
+    # the shared-memory-versus-wire comparison is part of the same run
+    for key in ("wire", "system_shm"):
+        assert line["extra"][key]["infer_per_sec"] > 0
+        assert line["extra"][key]["requests"] == 128 * gpus
 
 
 def test_single_rank_line():
-    cmd = [sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--requests-per-step", "64", "--concurrency", "16"]
+    cmd = [sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--requests-per-step", "64", "--concurrency", "16",
+           "--extra-requests", "128"]
     done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert done.returncode == 0, done.stderr[-2000:]
     _check(_json_line(done.stdout), 1, 3, 1)
@@ -46,7 +52,29 @@ def test_two_ranks_print_one_aggregate_line():
     env = dict(os.environ, TCA_BENCH_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--requests-per-step", "64", "--concurrency", "16"]
+           "--requests-per-step", "64", "--concurrency", "16",
+           "--extra-requests", "128"]
     done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
     assert done.returncode == 0, done.stderr[-2000:]
     _check(_json_line(done.stdout), 2, 3, 1)
+
+
+def test_gpus_flag_alone_starts_the_ranks():
+    """``python bench.py --gpus 2`` with no launcher: bench.py starts both ranks itself."""
+    env = dict(os.environ, TCA_BENCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--requests-per-step", "64",
+           "--concurrency", "16", "--extra-requests", "128"]
+    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
+    assert done.returncode == 0, done.stderr[-2000:]
+    line = _json_line(done.stdout)
+    _check(line, 2, 3, 1)
+    assert line["rank_backend"] == "gloo"
+
+
+def test_rank_count_must_match_gpus_flag():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    done = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1"], cwd=ROOT, capture_output=True,
+                          text=True, timeout=120, env=env)
+    assert done.returncode != 0 and "one rank per GPU" in done.stderr
