@@ -46,8 +46,8 @@ def test_graph_replay_equals_eager(model):
 
     x = torch.randn(8, 3, 224, 224, device="cuda", dtype=torch.float16)
     out = torch.empty(8, 1000, device="cuda", dtype=torch.float32)
-    model.run(x, out)
-    model.run(x, out)  # replay
+    model.run(x, out, stable=True)
+    model.run(x, out, stable=True)  # replay
     model.stream.synchronize()
     with torch.no_grad(), torch.cuda.stream(model.stream):
         eager = model._forward_eager(x)
@@ -67,19 +67,19 @@ def test_graphs_of_one_instance_share_their_activation_memory(model):
     outs = [torch.empty(8, 1000, device="cuda", dtype=torch.float32) for _ in range(6)]
     big_x = torch.randn(32, 3, 224, 224, device="cuda", dtype=torch.float16)
     big_out = torch.empty(32, 1000, device="cuda", dtype=torch.float32)
-    model.run(big_x, big_out)  # the largest batch sizes the pool
-    model.run(xs[0], outs[0])
+    model.run(big_x, big_out, stable=True)  # the largest batch sizes the pool
+    model.run(xs[0], outs[0], stable=True)
     model.stream.synchronize()
     before = torch.cuda.memory_reserved()
     for x, out in zip(xs[1:], outs[1:]):
-        model.run(x, out)
+        model.run(x, out, stable=True)
     model.stream.synchronize()
     grown = torch.cuda.memory_reserved() - before
     assert grown <= 8 << 20, f"five more batch-8 graphs reserved {grown >> 20} MiB"
     # replay in another order than captured, the large graph in between
     for i in (3, 0, 5):
-        model.run(xs[i], outs[i])
-        model.run(big_x, big_out)
+        model.run(xs[i], outs[i], stable=True)
+        model.run(big_x, big_out, stable=True)
     model.stream.synchronize()
     with torch.no_grad(), torch.cuda.stream(model.stream):
         eager = [model._forward_eager(xs[i]) for i in (3, 0, 5)]

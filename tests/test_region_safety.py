@@ -1,0 +1,172 @@
+"""Shared-memory references are validated before they address memory, and a region cannot be
+unmapped under a request that uses it.  The reference's clients send the offset / byte size as
+plain integers (``src/python/library/tritonclient/http/_infer_input.py:262-272``,
+``src/python/library/tritonclient/grpc/_utils.py:93-104``), so a server has to expect any value."""
+
+import json
+import threading
+import time
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture()
+def srv():
+    from triton_client_amd.server import Server
+
+    with Server(models=["simple", "custom_identity_int32"]) as s:
+        yield s
+
+
+def _region(key, nbytes):
+    import tritonclient.utils.shared_memory as shm
+
+    return shm.create_shared_memory_region(key.strip("/"), key, nbytes)
+
+
+@pytest.mark.parametrize("proto", ["http", "grpc"])
+@pytest.mark.parametrize("offset,size", [(-64, 64), (0, -64), (-1 << 40, 64)])
+def test_negative_offset_or_size_is_a_bad_request(srv, proto, offset, size):
+    import tritonclient.grpc as g
+    import tritonclient.http as h
+    import tritonclient.utils.shared_memory as shm
+    from tritonclient.utils import InferenceServerException
+
+    mod = h if proto == "http" else g
+    region = _region(f"/tca_neg_{proto}_{abs(offset) % 97}_{abs(size)}", 256)
+    try:
+        with mod.InferenceServerClient(srv.http_url if proto == "http" else srv.grpc_url) as c:
+            c.register_system_shared_memory("neg", region.key, 256)
+            shm.set_shared_memory_region(region, [np.arange(16, dtype=np.int32).reshape(1, 16)])
+            a = mod.InferInput("INPUT0", [1, 16], "INT32")
+            b = mod.InferInput("INPUT1", [1, 16], "INT32")
+            a.set_shared_memory("neg", 64, 0)
+            b.set_shared_memory("neg", 64, 0)
+            # the client API validates nothing here: patch the wire values
+            if proto == "http":
+                a._parameters["shared_memory_offset"] = offset
+                a._parameters["shared_memory_byte_size"] = size
+            else:
+                a._input.parameters["shared_memory_offset"].int64_param = offset
+                a._input.parameters["shared_memory_byte_size"].int64_param = size
+            with pytest.raises(InferenceServerException) as err:
+                c.infer("simple", [a, b])
+            assert "negative" in str(err.value)
+            # outputs are checked the same way
+            a.set_shared_memory("neg", 64, 0)
+            out = mod.InferRequestedOutput("OUTPUT0")
+            out.set_shared_memory("neg", 64, 128)
+            if proto == "http":
+                out._parameters["shared_memory_offset"] = offset
+                out._parameters["shared_memory_byte_size"] = size
+            else:
+                out._output.parameters["shared_memory_offset"].int64_param = offset
+                out._output.parameters["shared_memory_byte_size"].int64_param = size
+            with pytest.raises(InferenceServerException) as err:
+                c.infer("simple", [a, b], outputs=[out])
+            assert "negative" in str(err.value)
+            # and the server is still fine
+            a.set_shared_memory("neg", 64, 0)
+            res = c.infer("simple", [a, b])
+            np.testing.assert_array_equal(res.as_numpy("OUTPUT0"), 2 * np.arange(16, dtype=np.int32).reshape(1, 16))
+            c.unregister_system_shared_memory("neg")
+    finally:
+        shm.destroy_shared_memory_region(region)
+
+
+def test_negative_binary_data_size_is_a_bad_request(srv):
+    import http.client
+
+    head = json.dumps({"inputs": [
+        {"name": "INPUT0", "shape": [1, 16], "datatype": "INT32", "parameters": {"binary_data_size": -64}},
+        {"name": "INPUT1", "shape": [1, 16], "datatype": "INT32", "parameters": {"binary_data_size": 128}}]}).encode()
+    body = head + bytes(64)
+    host, port = srv.http_url.split(":")
+    conn = http.client.HTTPConnection(host, int(port))
+    conn.request("POST", "/v2/models/simple/infer", body=body,
+                 headers={"Inference-Header-Content-Length": str(len(head))})
+    resp = conn.getresponse()
+    assert resp.status == 400 and b"negative" in resp.read()
+    conn.close()
+
+
+def test_unregister_waits_for_requests_in_flight(srv):
+    """A request that reads a region is slowed down server-side; unregistering the region in
+    the meantime blocks until the request has been answered - the request succeeds and the
+    region is gone afterwards."""
+    import tritonclient.http as h
+    import tritonclient.utils.shared_memory as shm
+
+    region = _region("/tca_inflight", 128)
+    x = np.arange(16, dtype=np.int32).reshape(1, 16)
+    try:
+        with h.InferenceServerClient(srv.http_url, concurrency=2) as c:
+            c.load_model("custom_identity_int32", config=json.dumps(
+                {"parameters": {"delay_ms": {"string_value": "400"}}}))
+            c.register_system_shared_memory("busy", region.key, 128)
+            shm.set_shared_memory_region(region, [x])
+            inp = h.InferInput("INPUT0", [1, 16], "INT32")
+            inp.set_shared_memory("busy", 64, 0)
+            out = h.InferRequestedOutput("OUTPUT0")
+            out.set_shared_memory("busy", 64, 64)
+            result = {}
+
+            def call():
+                t0 = time.perf_counter()
+                try:
+                    with h.InferenceServerClient(srv.http_url) as c2:
+                        c2.infer("custom_identity_int32", [inp], outputs=[out])
+                    result["ok"] = time.perf_counter() - t0
+                except Exception as e:  # pragma: no cover - the assertion below reports it
+                    result["error"] = e
+
+            t = threading.Thread(target=call)
+            t.start()
+            time.sleep(0.1)  # the request is inside the server now
+            t0 = time.perf_counter()
+            c.unregister_system_shared_memory("busy")
+            waited = time.perf_counter() - t0
+            t.join()
+            assert "ok" in result, result
+            assert waited >= 0.2, f"unregister returned after {waited:.3f}s with a request in flight"
+            np.testing.assert_array_equal(shm.get_contents_as_numpy(region, np.int32, [1, 16], 64), x)
+            assert c.get_system_shared_memory_status() == []
+            c.load_model("custom_identity_int32")
+    finally:
+        shm.destroy_shared_memory_region(region)
+
+
+def test_busy_region_survives_an_unregister_that_times_out():
+    """With a drain limit shorter than the request, unregister fails with an 'in use' error
+    and the region stays registered and usable."""
+    from triton_client_amd.server.core import InferenceCore, InferRequest, InputTensor, ServerError, ShmRef
+
+    core = InferenceCore(models=["custom_identity_int32"])
+    region = _region("/tca_busy_timeout", 64)
+    try:
+        core.sysshm.drain_timeout_s = 0.05
+        core.sysshm.register("r", region.key, 0, 64)
+        lease = core.sysshm.acquire("r")
+        assert lease is not None
+        with pytest.raises(ServerError) as err:
+            core.sysshm.unregister("r")
+        assert "in use" in err.value.message
+        assert [s["name"] for s in core.sysshm.status()] == ["r"]
+        # a region that is being closed hands out no new leases, an open one does
+        req = InferRequest("custom_identity_int32",
+                           inputs=[InputTensor("INPUT0", "INT32", [1, 16], shm=ShmRef("r", 64, 0))])
+        resp = core.infer(req)
+        assert resp.outputs[0].shape == [1, 16] and lease.inflight == 1
+        core.sysshm.release(lease)
+        core.sysshm.unregister("r")
+        assert core.sysshm.status() == []
+        with pytest.raises(ServerError) as err:
+            core.infer(InferRequest("custom_identity_int32",
+                                    inputs=[InputTensor("INPUT0", "INT32", [1, 16], shm=ShmRef("r", 64, 0))]))
+        assert "Unable to find shared memory region" in err.value.message
+    finally:
+        import tritonclient.utils.shared_memory as shm
+
+        shm.destroy_shared_memory_region(region)
+        core.shutdown()

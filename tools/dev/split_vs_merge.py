@@ -33,12 +33,12 @@ for n in (8, 16, 32, 64):
     oab = torch.empty(2 * n, 1000, device="cuda")
 
     def merged():
-        m.run(xab, oab, 0)
+        m.run(xab, oab, 0, stable=True)
         m.stream_of(0).synchronize()
 
     def split():
-        m.run(xa, oa, 0)
-        m.run(xb, ob, 1)
+        m.run(xa, oa, 0, stable=True)
+        m.run(xb, ob, 1, stable=True)
         m.stream_of(0).synchronize()
         m.stream_of(1).synchronize()
 

@@ -33,15 +33,15 @@ def main():
         x = torch.randn(b, 3, 224, 224, device="cuda", dtype=torch.float16)
         out = torch.empty(b, 1000, device="cuda", dtype=torch.float32)
         t1 = time.time()
-        model.run(x, out)
+        model.run(x, out, stable=True)
         model.stream.synchronize()
         first = time.time() - t1
         for _ in range(5):
-            model.run(x, out)
+            model.run(x, out, stable=True)
         model.stream.synchronize()
         t2 = time.perf_counter()
         for _ in range(args.iters):
-            model.run(x, out)
+            model.run(x, out, stable=True)
         model.stream.synchronize()
         ms = (time.perf_counter() - t2) * 1e3 / args.iters
         print(f"batch {b:4d}: {ms:7.3f} ms/forward  {b / ms * 1e3:9.0f} img/s   (first call {first:.2f}s)", flush=True)

@@ -80,7 +80,7 @@ def main():
             out = torch.empty(b, 1000, device=dev, dtype=torch.float32)
 
             def fwd():
-                model.run(x, out)
+                model.run(x, out, stable=True)
                 model.stream.synchronize()
 
             timed(f"resnet50_fp16_graph_b{b}", fwd, iters=max(5, args.iters // 2))

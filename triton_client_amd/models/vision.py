@@ -140,11 +140,19 @@ def _is_channels_last(torch, t):
 
 
 class _GraphCache:
-    """LRU of captured HIP graphs keyed by (batch, in_ptr, out_ptr)."""
+    """LRU of captured HIP graphs keyed by (batch, in_ptr, out_ptr, instance).
+
+    A graph that leaves the cache (LRU eviction, or its buffers' region being unmapped) may
+    still be enqueued on its instance's stream: it is parked together with an event recorded
+    on that stream and destroyed only once the event has completed."""
 
     def __init__(self, capacity=512):
         self._items = OrderedDict()
         self._capacity = capacity
+        self._parked = []  # [(event, graph entry)]
+
+    def __len__(self):
+        return len(self._items)
 
     def get(self, key):
         item = self._items.get(key)
@@ -152,10 +160,27 @@ class _GraphCache:
             self._items.move_to_end(key)
         return item
 
-    def put(self, key, value):
+    def put(self, key, value, retire=None):
+        """``retire(key) -> event`` records an event behind everything enqueued for ``key``."""
         self._items[key] = value
         while len(self._items) > self._capacity:
-            self._items.popitem(last=False)
+            old_key, old = self._items.popitem(last=False)
+            self._park(old_key, old, retire)
+        self.collect()
+
+    def evict_if(self, predicate, retire=None):
+        for key in [k for k, v in self._items.items() if predicate(k, v)]:
+            self._park(key, self._items.pop(key), retire)
+        self.collect()
+
+    def _park(self, key, value, retire):
+        event = retire(key) if retire is not None else None
+        if event is None:
+            return  # nothing can be in flight: drop it now
+        self._parked.append((event, value))
+
+    def collect(self):
+        self._parked = [(e, v) for e, v in self._parked if not e.query()]
 
 
 # GPU models of this process by name: ensembles resolve their steps here
@@ -184,8 +209,9 @@ class ResNet50(Model):
             self.warmup_batches = tuple(range(8, self.max_batch_size + 1, 8))
         self._torch = None
         self._net = None
-        self._graphs = _GraphCache()
-        self._lock = threading.Lock()
+        self._graphs = _GraphCache(int(os.environ.get("TCA_RESNET_GRAPH_CACHE", "512")))
+        self._io_buffers = {}  # (instance, batch) -> static (input, output) pair for callers without stable buffers
+        self._lock = threading.RLock()
         self._stream = None
         self.labels = [f"class_{i}" for i in range(1000)]
         self.use_graphs = True
@@ -258,7 +284,8 @@ class ResNet50(Model):
     def unload(self):
         if _LOADED.get(self.name) is self:
             del _LOADED[self.name]
-        self._graphs = _GraphCache()
+        self._graphs = _GraphCache(int(os.environ.get("TCA_RESNET_GRAPH_CACHE", "512")))
+        self._io_buffers = {}
         self._graph_pools = [None] * len(getattr(self, "_graph_pools", []))
         self._net = None
         if self._torch is not None:
@@ -450,29 +477,69 @@ class ResNet50(Model):
         logits = self._net.fc(feats)
         out.copy_(logits)  # fp16 -> fp32 cast fused into the copy kernel
 
-    def run(self, x, out=None, instance=0):
+    def run(self, x, out=None, instance=0, stable=False):
         """Forward ``x`` ([B,3,224,224] fp16 on this GPU).  When ``out`` (fp32
         [B,1000]) is given the logits are written there.  Work is enqueued on
         the stream of execution instance ``instance``; the caller synchronises
-        via ``self.stream_of(instance)`` (``self.stream`` for instance 0)."""
+        via ``self.stream_of(instance)`` (``self.stream`` for instance 0).
+
+        ``stable=True`` promises that ``x`` and ``out`` are long-lived buffers (a registered
+        shared-memory region, the batcher's static buffers): a graph is captured for exactly
+        these addresses and replayed on later calls.  Otherwise the tensors are copied through
+        one pair of static buffers per (instance, batch) and that pair's graph is replayed, so
+        callers with fresh tensors on every call neither capture nor retain anything per call."""
         torch = self._torch
         batch = x.shape[0]
         stream = self._streams[instance]
-        if out is None:
-            out = torch.empty(batch, 1000, device=self._device, dtype=torch.float32)
         if not self.use_graphs:
+            if out is None:
+                out = torch.empty(batch, 1000, device=self._device, dtype=torch.float32)
             with torch.no_grad(), torch.cuda.stream(stream):
                 self._forward_into(x, out)
+            return out
+        if not (stable and out is not None):
+            with self._lock:
+                bufs = self._io_buffers.get((instance, batch))
+                if bufs is None:
+                    bufs = self._io_buffers[(instance, batch)] = (
+                        torch.empty(batch, 3, 224, 224, device=self._device, dtype=torch.float16),
+                        torch.empty(batch, 1000, device=self._device, dtype=torch.float32))
+            sx, sout = bufs
+            # the caller produced x on its own stream; results are handed back on the instance stream
+            stream.wait_stream(torch.cuda.current_stream(self._device))
+            with torch.cuda.stream(stream):
+                sx.copy_(x, non_blocking=True)
+            self.run(sx, sout, instance, stable=True)
+            with torch.cuda.stream(stream):
+                if out is None:
+                    out = torch.empty(batch, 1000, device=self._device, dtype=torch.float32)
+                    out.record_stream(stream)
+                out.copy_(sout, non_blocking=True)
             return out
         key = (batch, x.data_ptr(), out.data_ptr(), instance)
         with self._lock:
             graph = self._graphs.get(key)
             if graph is None:
                 graph = self._capture(x, out, stream, instance)
-                self._graphs.put(key, graph)
+                self._graphs.put(key, graph, self._retire_event)
             with torch.cuda.stream(stream), _trace.range(f"resnet50 graph replay b={batch}"):
                 graph[0].replay()
         return out
+
+    def _retire_event(self, key):
+        event = self._torch.cuda.Event()
+        event.record(self._streams[key[3]])
+        return event
+
+    def evict_region(self, base, nbytes):
+        """Drop every captured graph that reads or writes ``[base, base + nbytes)`` (a
+        shared-memory mapping that is about to be closed)."""
+        end = base + nbytes
+        with self._lock:
+            self._graphs.evict_if(lambda k, v: base <= k[1] < end or base <= k[2] < end, self._retire_event)
+
+    def graph_count(self):
+        return len(self._graphs)
 
     def _capture(self, x, out, stream, instance=0):
         """Capture one forward as a HIP graph.  All graphs of one execution instance allocate
@@ -512,7 +579,9 @@ class ResNet50(Model):
             raise ModelError(f"unexpected shape for input 'input' for model 'resnet50'. Expected [-1,3,224,224], "
                              f"got {list(x.shape)}")
         out = inputs.get("__out__output")  # preallocated destination (e.g. a hipshm view)
-        result = self.run(x, out, inputs.get("__instance__", 0))
+        # the server only hands over long-lived buffers together with a destination: regions
+        # registered by clients or the batcher's static buffers
+        result = self.run(x, out, inputs.get("__instance__", 0), stable=out is not None)
         return {"output": result}
 
 

@@ -51,7 +51,7 @@ def _profiled(fn, tag):
 
 class _Item:
     __slots__ = ("req", "inputs", "batch", "stable", "requested", "ctx", "stats", "t_arrive", "version", "done",
-                 "response", "error", "t_queued", "callback", "gap_ns")
+                 "response", "error", "t_queued", "callback", "gap_ns", "release")
 
     def __init__(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback=None):
         self.req, self.inputs, self.batch, self.stable = req, inputs, batch, stable
@@ -63,9 +63,13 @@ class _Item:
         self.error = None
         self.t_queued = time.perf_counter_ns()
         self.gap_ns = 1 << 62  # time since the previous arrival for the same model (set by the batcher)
+        self.release = None  # gives back the request's shared-memory region leases
 
     def finish(self):
-        """Hand the outcome to whoever submitted the request."""
+        """Hand the outcome to whoever submitted the request.  The GPU work and the copies of
+        this request are complete here, so its shared-memory regions may be unmapped again."""
+        if self.release is not None:
+            self.release(self.req)
         if self.callback is None:
             self.done.set()
             return
@@ -177,6 +181,7 @@ class DynamicBatcher:
     # called on transport threads
     def submit(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version):
         item = _Item(req, inputs, max(1, batch), stable, requested, ctx, stats, t_arrive, version)
+        item.release = self.core.release_request
         self._stamp(item)
         self.q.put(item)
         item.done.wait()
@@ -188,6 +193,7 @@ class DynamicBatcher:
         """Queue a request and return at once; ``callback(response, error)`` runs
         on the completer thread (or the batcher thread when the launch fails)."""
         item = _Item(req, inputs, max(1, batch), stable, requested, ctx, stats, t_arrive, version, callback)
+        item.release = self.core.release_request
         self._stamp(item)
         self.q.put(item)
 

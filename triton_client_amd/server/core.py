@@ -68,6 +68,15 @@ class ShmRef:
     byte_size: int
     offset: int = 0
 
+    def __post_init__(self):
+        # both values arrive as signed integers (JSON numbers, int64 protobuf fields): a
+        # negative one would pass every "offset + size <= region" check and address memory
+        # in front of the region
+        if self.byte_size < 0 or self.offset < 0:
+            raise ServerError(
+                f"shared memory offset and byte size must not be negative for region '{self.region}' "
+                f"(offset {self.offset}, byte size {self.byte_size})", 400)
+
 
 @dataclass
 class InputTensor:
@@ -187,12 +196,86 @@ class ModelStats:
 # --------------------------------------------------------------------------
 # shared memory registries
 # --------------------------------------------------------------------------
-class SystemShmRegistry:
-    def __init__(self):
-        self._lock = threading.Lock()
-        self._regions = {}
+class _Leased:
+    """Lease bookkeeping shared by both shared-memory registries.
 
+    A request that names a region holds a lease on it from validation until its answer has
+    been produced (queued in the batcher, running on the GPU, being copied out).  Unregister
+    first stops new leases, then waits for the outstanding ones; a region that is still busy
+    after ``drain_timeout_s`` stays registered and the call fails with an "in use" error."""
+
+    def __init__(self, drain_timeout_s=10.0):
+        self._lock = threading.Lock()
+        self._idle = threading.Condition(self._lock)
+        self._regions = {}
+        self.drain_timeout_s = drain_timeout_s
+
+    def acquire(self, name):
+        """Lease on region ``name`` (None when it is not registered or is being unregistered).
+        Every successful acquire is paired with one :meth:`release`."""
+        with self._lock:
+            entry = self._regions.get(name)
+            if entry is None or entry.closing:
+                return None
+            entry.inflight += 1
+            return entry
+
+    def release(self, entry):
+        with self._lock:
+            entry.inflight -= 1
+            if entry.inflight <= 0:
+                self._idle.notify_all()
+
+    def _drain(self, name):
+        """Under ``self._lock``: mark the named region (all when empty) as closing, wait for
+        their leases and remove the idle ones.  Returns ``(removed [(name, entry)], busy [name])``."""
+        names = [name] if name else list(self._regions)
+        entries = []
+        for n in names:
+            entry = self._regions.get(n)
+            if entry is not None and not entry.closing:
+                entry.closing = True  # no new leases from here on
+                entries.append((n, entry))
+        deadline = time.monotonic() + self.drain_timeout_s
+        removed, busy = [], []
+        for n, entry in entries:
+            while entry.inflight > 0:
+                remaining = deadline - time.monotonic()
+                if remaining <= 0:
+                    break
+                self._idle.wait(remaining)
+            if entry.inflight > 0:
+                entry.closing = False  # still serving requests: leave it registered
+                busy.append(n)
+            else:
+                del self._regions[n]
+                removed.append((n, entry))
+        return removed, busy
+
+    @staticmethod
+    def _raise_busy(busy):
+        if busy:
+            raise ServerError(
+                f"Cannot unregister shared memory region '{busy[0]}': it is in use by in-flight inference requests",
+                400)
+
+
+class _SystemRegion:
+    __slots__ = ("key", "offset", "byte_size", "handle", "inflight", "closing")
+
+    def __init__(self, key, offset, byte_size, handle):
+        self.key, self.offset, self.byte_size, self.handle = key, int(offset), int(byte_size), handle
+        self.inflight = 0
+        self.closing = False
+
+    def __getitem__(self, i):
+        return (self.key, self.offset, self.byte_size, self.handle)[i]
+
+
+class SystemShmRegistry(_Leased):
     def register(self, name, key, offset, byte_size):
+        if int(offset) < 0 or int(byte_size) < 0:
+            raise ServerError(f"Unable to open shared memory region: '{key}': negative offset or byte size", 400)
         with self._lock:
             if name in self._regions:
                 raise ServerError(f"shared memory region '{name}' already in manager", 400)
@@ -200,18 +283,17 @@ class SystemShmRegistry:
                 handle = sysshm.attach_shared_memory_region(name, key, byte_size, offset)
             except sysshm.SharedMemoryException as e:
                 raise ServerError(f"Unable to open shared memory region: '{key}': {e}", 400) from None
-            self._regions[name] = (key, int(offset), int(byte_size), handle)
+            self._regions[name] = _SystemRegion(key, offset, byte_size, handle)
 
     def unregister(self, name=""):
         with self._lock:
-            names = [name] if name else list(self._regions)
-            for n in names:
-                entry = self._regions.pop(n, None)
-                if entry is not None:
-                    try:
-                        sysshm.destroy_shared_memory_region(entry[3])
-                    except sysshm.SharedMemoryException:
-                        pass
+            removed, busy = self._drain(name)
+        for _, entry in removed:
+            try:
+                sysshm.destroy_shared_memory_region(entry.handle)
+            except sysshm.SharedMemoryException:
+                pass
+        self._raise_busy(busy)
 
     def status(self, name=""):
         with self._lock:
@@ -230,19 +312,42 @@ class SystemShmRegistry:
         if entry is None:
             return None
         size = entry[2]
-        if ref.offset + ref.byte_size > size:
+        if ref.offset < 0 or ref.byte_size < 0 or ref.offset + ref.byte_size > size:
             raise ServerError(
                 f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
         return entry[3].buffer()[ref.offset: ref.offset + ref.byte_size]
 
 
-class DeviceShmRegistry:
-    """Regions opened from HIP IPC handles (protocol name: cudasharedmemory)."""
+class _DeviceRegion:
+    """One registered device region: ``(device_id, byte_size, mapping)`` for the callers that
+    index it like the tuple it used to be, plus the number of requests that currently hold it."""
 
-    def __init__(self):
-        self._lock = threading.Lock()
-        self._regions = {}
+    __slots__ = ("device_id", "byte_size", "mapping", "inflight", "closing")
+
+    def __init__(self, device_id, byte_size, mapping):
+        self.device_id, self.byte_size, self.mapping = int(device_id), int(byte_size), mapping
+        self.inflight = 0
+        self.closing = False
+
+    def __getitem__(self, i):
+        return (self.device_id, self.byte_size, self.mapping)[i]
+
+    def __iter__(self):
+        return iter((self.device_id, self.byte_size, self.mapping))
+
+
+class DeviceShmRegistry(_Leased):
+    """Regions opened from HIP IPC handles (protocol name: cudasharedmemory).
+
+    Unregister waits for the leases of in-flight requests (see :class:`_Leased`), drops every
+    cached view, asks the loaded models to drop captured graphs that address the region
+    (``on_close`` hooks) and only then closes the IPC mapping: the GPU never replays a graph
+    or runs a copy on an unmapped address."""
+
+    def __init__(self, drain_timeout_s=10.0):
+        super().__init__(drain_timeout_s)
         self._views = {}  # (region, datatype, shape, offset) -> torch view; building one costs ~20 us
+        self.on_close = []  # callables (base address, byte size): a mapping is about to be closed
 
     def tensor_view(self, name, mapping, datatype, shape, offset):
         """Torch view of a slice of a registered region, cached: requests of a
@@ -252,9 +357,12 @@ class DeviceShmRegistry:
         if view is None:
             from ..utils import hip_shared_memory as hipshm
 
-            view = hipshm.mapping_as_torch(mapping, datatype, shape, offset)
+            try:
+                view = hipshm.mapping_as_torch(mapping, datatype, shape, offset)
+            except ValueError as e:
+                raise ServerError(f"invalid tensor in shared memory region '{name}': {e}", 400) from None
             with self._lock:
-                if name in self._regions and self._regions[name][2] is mapping:
+                if name in self._regions and self._regions[name].mapping is mapping:
                     if len(self._views) > 65536:
                         self._views.clear()
                     self._views[key] = view
@@ -263,6 +371,8 @@ class DeviceShmRegistry:
     def register(self, name, raw_handle: bytes, device_id, byte_size):
         from ..utils import hip_shared_memory as hipshm
 
+        if int(byte_size) < 0 or int(device_id) < 0:
+            raise ServerError(f"failed to register device shared memory region '{name}': negative size or device", 400)
         with self._lock:
             if name in self._regions:
                 raise ServerError(f"shared memory region '{name}' already in manager", 400)
@@ -271,22 +381,28 @@ class DeviceShmRegistry:
                     mapping = hipshm.open_shared_memory_region(name, raw_handle, byte_size, device_id)
             except Exception as e:
                 raise ServerError(f"failed to register device shared memory region '{name}': {e}", 400) from None
-            self._regions[name] = (int(device_id), int(byte_size), mapping)
+            self._regions[name] = _DeviceRegion(device_id, byte_size, mapping)
 
     def unregister(self, name=""):
         from ..utils import hip_shared_memory as hipshm
 
         with self._lock:
-            names = [name] if name else list(self._regions)
-            for n in names:
-                entry = self._regions.pop(n, None)
-                if entry is not None:
-                    for key in [k for k in self._views if k[0] == n]:
-                        del self._views[key]
-                    try:
-                        hipshm.close_shared_memory_region(entry[2])
-                    except Exception:
-                        pass
+            removed, busy = self._drain(name)
+            for n, _ in removed:
+                for key in [k for k in self._views if k[0] == n]:
+                    del self._views[key]
+        for n, entry in removed:
+            base, size = entry.mapping.address, entry.byte_size
+            for hook in list(self.on_close):
+                try:
+                    hook(base, size)
+                except Exception:
+                    pass
+            try:
+                hipshm.close_shared_memory_region(entry.mapping)
+            except Exception:
+                pass
+        self._raise_busy(busy)
 
     def status(self, name=""):
         with self._lock:
@@ -296,9 +412,10 @@ class DeviceShmRegistry:
                 items = {name: self._regions[name]}
             else:
                 items = dict(self._regions)
-        return [{"name": n, "device_id": e[0], "byte_size": e[1]} for n, e in items.items()]
+        return [{"name": n, "device_id": e.device_id, "byte_size": e.byte_size} for n, e in items.items()]
 
     def get(self, name):
+        """Entry of region ``name`` for a caller that holds a lease on it (see ``acquire``)."""
         with self._lock:
             return self._regions.get(name)
 
@@ -355,6 +472,16 @@ def _decode_json(datatype, shape, data, name):
 
 
 ASYNC = object()  # returned by InferenceCore.infer when the answer comes through on_done
+
+
+class _UnstableDeviceTensor:
+    """Marks a device tensor that was copied out of a shared-memory region (so its address is
+    not that of the region and must not key a captured graph)."""
+
+    __slots__ = ("tensor",)
+
+    def __init__(self, tensor):
+        self.tensor = tensor
 
 
 class PackedBytes:
@@ -490,6 +617,8 @@ class InferenceCore:
         except ModelError as e:
             raise ServerError(f"failed to load '{name}': {e}", 400) from None
         lm = LoadedModel(model, self.gpu)
+        if hasattr(model, "evict_region"):
+            self.devshm.on_close.append(model.evict_region)
         if model.device == "gpu" and model.dynamic_batching:
             from .batcher import DynamicBatcher
 
@@ -502,6 +631,9 @@ class InferenceCore:
             self._retire(old)
 
     def _retire(self, lm):
+        hook = getattr(lm.model, "evict_region", None)
+        if hook in self.devshm.on_close:
+            self.devshm.on_close.remove(hook)
         if lm.batcher is not None:
             lm.batcher.stop()
         try:
@@ -638,7 +770,9 @@ class InferenceCore:
                     f"unexpected shape for input '{t.name}' for model '{model.name}'. Expected {dims}, got {shape}")
             if t.shm is not None:
                 arr = self._read_shm(t, shape, model, gpu, deferred)
-                if gpu and not isinstance(arr, np.ndarray) and arr is not None:
+                if isinstance(arr, _UnstableDeviceTensor):
+                    arr = arr.tensor
+                elif gpu and not isinstance(arr, np.ndarray) and arr is not None:
                     stable.add(t.name)
             elif t.data is not None:
                 arr = t.data
@@ -679,7 +813,26 @@ class InferenceCore:
         if ref.offset + ref.byte_size > size:
             raise ServerError(f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
         if gpu and t.datatype != "BYTES":
-            return self.devshm.tensor_view(ref.region, mapping, t.datatype, shape, ref.offset)
+            itemsize = 2 if t.datatype == "BF16" else np.dtype(triton_to_np_dtype(t.datatype)).itemsize
+            need = (int(np.prod(shape)) if len(shape) else 1) * itemsize
+            if need > ref.byte_size:
+                raise ServerError(
+                    f"input '{t.name}' for model '{model.name}' needs {need} bytes, but the request gives it "
+                    f"{ref.byte_size} bytes of shared memory region '{ref.region}'", 400)
+            if (mapping.address + ref.offset) % itemsize:
+                raise ServerError(
+                    f"shared memory offset {ref.offset} of input '{t.name}' is not a multiple of the element size "
+                    f"({itemsize})", 400)
+            view = self.devshm.tensor_view(ref.region, mapping, t.datatype, shape, ref.offset)
+            if (mapping.address + ref.offset) % 16:
+                # the fused kernels load 4- to 16-byte words from the input: a tensor at an odd
+                # offset is copied to an aligned buffer (and is no longer a stable address)
+                import torch
+
+                copy = view.clone()
+                torch.cuda.current_stream(copy.device).synchronize()  # consumers run on other streams
+                return _UnstableDeviceTensor(copy)
+            return view
         deferred.append((t, shape, mapping, ref))  # read together with the request's other ranges
         return None
 
@@ -698,6 +851,8 @@ class InferenceCore:
             raise ServerError(
                 f"shared memory size specified with the request for output '{ro.name}' ({ro.shm.byte_size} bytes) "
                 f"should be at least {need} bytes to hold the results")
+        if (entry[2].address + ro.shm.offset) % 16:
+            return None  # odd offset: the kernels write an aligned buffer, the result is copied into the region
         return self.devshm.tensor_view(ro.shm.region, entry[2], spec.datatype, shape, ro.shm.offset)
 
     def _sequence_ctx(self, lm, req):
@@ -766,6 +921,38 @@ class InferenceCore:
         return bool(getattr(model, "inline", False)) and model.device == "cpu" and not model.parameters \
             and not model.decoupled
 
+    def _lease_regions(self, req):
+        """Take a lease on every shared-memory region the request names, so none of them
+        can be unmapped until :meth:`release_request` runs (after the answer is complete)."""
+        names = []
+        for t in req.inputs:
+            if t.shm is not None and t.shm.region not in names:
+                names.append(t.shm.region)
+        for ro in req.outputs or ():
+            if ro.shm is not None and ro.shm.region not in names:
+                names.append(ro.shm.region)
+        if not names:
+            return
+        leases = req._leases = []
+        for n in names:
+            entry = self.sysshm.acquire(n)
+            registry = self.sysshm
+            if entry is None:
+                entry = self.devshm.acquire(n)
+                registry = self.devshm
+            if entry is None:
+                self.release_request(req)
+                raise ServerError(f"Unable to find shared memory region: '{n}'", 400)
+            leases.append((registry, entry))
+
+    def release_request(self, req):
+        """Give back the request's region leases (idempotent)."""
+        leases = getattr(req, "_leases", None)
+        if leases:
+            req._leases = None
+            for registry, entry in leases:
+                registry.release(entry)
+
     def infer(self, req: InferRequest, on_done=None):
         """Run one request.  Returns an :class:`InferResponse` for ordinary
         models, or an iterator of them for decoupled models.
@@ -779,7 +966,9 @@ class InferenceCore:
         model = lm.model
         version = req.model_version or model.versions[-1]
         stats = lm.stats[version]
+        handed_over = False  # the leases travel with the request (batcher item / response generator)
         try:
+            self._lease_regions(req)
             if model.decoupled and not req.streaming:
                 raise ServerError(
                     f"doesn't support models with decoupled transaction policy: model '{model.name}' must be called "
@@ -802,6 +991,7 @@ class InferenceCore:
             if model.device == "gpu":
                 if lm.batcher is not None:
                     if on_done is not None:
+                        handed_over = True  # released by the batcher when the answer is complete
                         lm.batcher.submit_async(req, inputs, batch, stable, requested, ctx, stats, t_arrive, version,
                                                 on_done)
                         return ASYNC
@@ -813,6 +1003,7 @@ class InferenceCore:
                 result = model.execute(inputs, ctx)
                 t2 = time.perf_counter_ns()
             if model.decoupled:
+                handed_over = True  # released when the response generator ends
                 return self._decoupled_iter(lm, req, result, requested, out_specs, version, stats, t_arrive)
             response = self._build_response(lm, req, result, requested, out_specs, version, batch)
             t3 = time.perf_counter_ns()
@@ -824,6 +1015,9 @@ class InferenceCore:
         except ServerError:
             stats.record_fail(time.perf_counter_ns() - t_arrive)
             raise
+        finally:
+            if not handed_over:
+                self.release_request(req)
 
     # -- GPU helpers (torch imported lazily: CPU-only servers never need it) --
     def _to_device(self, lm, inputs, stable):
@@ -881,6 +1075,8 @@ class InferenceCore:
             except ModelError as e:
                 stats.record_fail(time.perf_counter_ns() - t_arrive)
                 raise ServerError(str(e), 400) from None
+            finally:
+                self.release_request(req)
 
         return gen()
 

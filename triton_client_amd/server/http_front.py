@@ -79,6 +79,8 @@ def parse_infer_body(model, version, body, header_length):
                            int(params.get("shared_memory_offset", 0)))
         elif "binary_data_size" in params:
             size = int(params["binary_data_size"])
+            if size < 0:
+                raise ServerError(f"negative binary_data_size for input '{t.name}'", 400)
             if cursor + size > len(tail):
                 raise ServerError(f"unexpected end of binary data for input '{t.name}'", 400)
             t.raw = tail[cursor: cursor + size]
