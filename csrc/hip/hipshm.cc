@@ -296,7 +296,16 @@ int tca_hip_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
   return 0;
 }
 
+int tca_hipshm_create_ex(const char* name, uint64_t byte_size, int device, int fine_grained, void** out);
+
 int tca_hipshm_create(const char* name, uint64_t byte_size, int device, void** out) {
+  return tca_hipshm_create_ex(name, byte_size, device, 0, out);
+}
+
+// fine_grained != 0: memory that stays coherent between GPUs (and processes) while kernels
+// run - for flags that one GPU sets and another polls; zero-filled.  Plain regions are the
+// default: their contents are exchanged at kernel boundaries.
+int tca_hipshm_create_ex(const char* name, uint64_t byte_size, int device, int fine_grained, void** out) {
   if (!name || !out) return FailMsg("invalid argument");
   auto* r = new Region();
   r->name = name;
@@ -316,8 +325,18 @@ int tca_hipshm_create(const char* name, uint64_t byte_size, int device, void** o
     return FailMsg("region of " + std::to_string(byte_size) + " bytes does not fit in the " +
                    std::to_string(free_b) + " bytes free on device " + std::to_string(device));
   }
-  hipError_t e = hipMalloc(&r->ptr, byte_size ? byte_size : 1);
-  if (e != hipSuccess) { delete r; return Fail("hipMalloc", e); }
+  hipError_t e;
+  if (fine_grained) {
+    e = hipExtMallocWithFlags(&r->ptr, byte_size ? byte_size : 1, hipDeviceMallocFinegrained);
+    if (e == hipSuccess) {
+      e = hipMemset(r->ptr, 0, byte_size ? byte_size : 1);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e != hipSuccess) (void)hipFree(r->ptr);
+    }
+  } else {
+    e = hipMalloc(&r->ptr, byte_size ? byte_size : 1);
+  }
+  if (e != hipSuccess) { delete r; return Fail(fine_grained ? "hipExtMallocWithFlags" : "hipMalloc", e); }
   hipIpcMemHandle_t h;
   e = hipIpcGetMemHandle(&h, r->ptr);
   if (e != hipSuccess) {

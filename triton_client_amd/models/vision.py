@@ -259,6 +259,10 @@ class ResNet50(Model):
                 if isinstance(m, torch.nn.BatchNorm2d):
                     m.running_var.fill_(1.0)
                     m.running_mean.zero_()
+                elif getattr(m, "bias", None) is not None and m.bias.dim() == 1:
+                    # from the same generator: every replica of the model (other processes,
+                    # other GPUs) holds the same weights
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.01)
         net.eval()
         net.fold_batchnorm()
         net = net.to(self._device, dtype=torch.float16).to(memory_format=torch.channels_last)
@@ -509,13 +513,20 @@ class ResNet50(Model):
             stream.wait_stream(torch.cuda.current_stream(self._device))
             with torch.cuda.stream(stream):
                 sx.copy_(x, non_blocking=True)
-            self.run(sx, sout, instance, stable=True)
+            self._run_stable(sx, sout, instance)
             with torch.cuda.stream(stream):
                 if out is None:
                     out = torch.empty(batch, 1000, device=self._device, dtype=torch.float32)
                     out.record_stream(stream)
                 out.copy_(sout, non_blocking=True)
             return out
+        return self._run_stable(x, out, instance)
+
+    def _run_stable(self, x, out, instance):
+        """Replay (capturing on first use) the graph of exactly these long-lived buffers."""
+        torch = self._torch
+        batch = x.shape[0]
+        stream = self._streams[instance]
         key = (batch, x.data_ptr(), out.data_ptr(), instance)
         with self._lock:
             graph = self._graphs.get(key)

@@ -57,6 +57,16 @@ def install(lib):
     lib.tca_hipshm_destroy.argtypes = [c_void_p]
     lib.tca_hipshm_open.restype = c_int
     lib.tca_hipshm_open.argtypes = [c_char_p, c_char_p, c_uint64, c_int, POINTER(c_void_p)]
+    lib.tca_flag_error.restype = c_char_p
+    lib.tca_flag_error.argtypes = []
+    lib.tca_hipshm_create_ex.restype = c_int
+    lib.tca_hipshm_create_ex.argtypes = [c_char_p, c_uint64, c_int, c_int, POINTER(c_void_p)]
+    lib.tca_can_stream_wait_value.restype = c_int
+    lib.tca_can_stream_wait_value.argtypes = [c_int, POINTER(c_int)]
+    lib.tca_flag_set.restype = c_int
+    lib.tca_flag_set.argtypes = [c_void_p, c_void_p, c_uint32, c_int]
+    lib.tca_flag_wait.restype = c_int
+    lib.tca_flag_wait.argtypes = [c_void_p, c_void_p, c_uint32, c_int, c_uint32, c_void_p]
     lib.tca_hip_device_synchronize.restype = c_int
     lib.tca_hip_device_synchronize.argtypes = [c_int]
 

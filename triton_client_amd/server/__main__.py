@@ -39,7 +39,7 @@ def main(argv=None):
     else:
         models = list(DEFAULT_CPU_MODELS)
         if args.gpu is not None:
-            models += [n for n, c in MODEL_ZOO.items() if c.device == "gpu"]
+            models += [n for n, c in MODEL_ZOO.items() if c.device == "gpu" and getattr(c, "autoload", True)]
     server = Server(models=models, gpu=args.gpu, http_port=args.http_port, grpc_port=args.grpc_port, host=args.host,
                     model_control=args.model_control_mode, http_workers=args.http_workers,
                     grpc_workers=args.grpc_workers, grpc_impl=args.grpc_impl, grpc_reactors=args.grpc_reactors, tls_cert=args.tls_cert,

@@ -149,11 +149,14 @@ def device_memory_info(device_id=0):
     return free.value, total.value
 
 
-def create_shared_memory_region(triton_shm_name, byte_size, device_id):
-    """Allocate ``byte_size`` bytes on GPU ``device_id`` and export an IPC handle."""
+def create_shared_memory_region(triton_shm_name, byte_size, device_id, fine_grained=False):
+    """Allocate ``byte_size`` bytes on GPU ``device_id`` and export an IPC handle.
+
+    ``fine_grained=True`` (not in the reference API) asks for zero-filled memory that stays
+    coherent between GPUs while kernels run: for flags that one GPU sets and another polls."""
     h = c_void_p()
     name = triton_shm_name.encode("utf-8") if isinstance(triton_shm_name, str) else bytes(triton_shm_name)
-    rc = _lib().tca_hipshm_create(name, int(byte_size), int(device_id), byref(h))
+    rc = _lib().tca_hipshm_create_ex(name, int(byte_size), int(device_id), 1 if fine_grained else 0, byref(h))
     _check(rc, "unable to create device shared memory handle")
     region = HipSharedMemoryRegion(h)
     region._name = triton_shm_name
