@@ -59,6 +59,14 @@ def parse_args():
                     help="native: C++ load generator (tca_loadgen) over the in-tree gRPC/HTTP client; "
                          "python: tritonclient-API threads in this process")
     ap.add_argument("--connections", type=int, default=4, help="gRPC channels the native load generator spreads over")
+    ap.add_argument("--mode", choices=["serve", "fanout"], default="serve",
+                    help="fanout: also measure resnet50_sharded (one request's batch split over the GPUs), "
+                         "reported under extra.fanout; runs by itself when there are several ranks")
+    ap.add_argument("--fanout-devices", default=None,
+                    help="GPU ordinals of the fan-out replicas besides GPU 0 (default: every other rank's GPU; "
+                         "'0,0' rehearses three replicas on one GPU)")
+    ap.add_argument("--fanout-modes", default="direct,rccl")
+    ap.add_argument("--fanout-requests", type=int, default=384)
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=os.environ.get("TCA_BENCH_DIST_BACKEND", "nccl"),
                     help="nccl (= RCCL) for one rank per GPU; gloo only to rehearse several ranks on ONE GPU, "
                          "which RCCL refuses")
@@ -70,7 +78,8 @@ if not os.path.exists(LOADGEN):
     LOADGEN = os.path.join(ROOT, "build", "bin", "tca_loadgen")
 
 
-def measure_native(args, url, device, dist, label, mode=None, steps=None, per_step=None, warmup_requests=None):
+def measure_native(args, url, device, dist, label, mode=None, steps=None, per_step=None, warmup_requests=None,
+                   model=None, batch=None, concurrency=None):
     """Closed loop driven by the C++ load generator.  This process only prepares
     the tensors (HIP preprocessing kernel -> HIP shared-memory regions, or system
     shared memory, or nothing for tensors on the wire), registers the regions and
@@ -93,14 +102,23 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
         raise SystemExit(f"{LOADGEN} is missing: run `python -m triton_client_amd._build cpp`")
     import tritonclient.grpc as grpcclient
 
-    b = args.batch
+    b = batch or args.batch
+    model = model or args.model
+    concurrency = concurrency or args.concurrency
     in_bytes, out_bytes = b * 3 * 224 * 224 * 2, b * 1000 * 4
     rng = np.random.default_rng(1234 + device)
     images = [rng.integers(0, 256, size=(375, 500, 3), dtype=np.uint8) for _ in range(b)]
-    pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=device)
+    pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=device, max_batch=max(8, min(b, 64)))
     control = grpcclient.InferenceServerClient(url if args.protocol == "grpc" else args.control_url)
     regions = []
     cleanup = []
+    tiled = None
+    if b > 64:
+        # large batches (fan-out runs): the kernel's output for 8 images, repeated
+        x8 = torch.empty(8, 3, 224, 224, device=f"cuda:{device}", dtype=torch.float16)
+        pre(images[:8], x8)
+        tiled = x8.repeat(-(-b // 8), 1, 1, 1)[:b].contiguous()
+        torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -109,17 +127,20 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
 
     proc = None
     try:
-        cmd = [LOADGEN, "-u", url, "-i", args.protocol, "-m", args.model, "-c", str(args.concurrency), "-b", str(b),
+        cmd = [LOADGEN, "-u", url, "-i", args.protocol, "-m", model, "-c", str(concurrency), "-b", str(b),
                "--connections", str(args.connections), "--count", str(steps * per_step), "--warmup-count",
                str(warmup_requests), "--wait-go"]
         if mode == "hip":
             import tritonclient.utils.cuda_shared_memory as hipshm
 
-            for i in range(args.concurrency):
+            for i in range(concurrency):
                 hin = hipshm.create_shared_memory_region(f"in_{device}_{i}", in_bytes, device)
                 hout = hipshm.create_shared_memory_region(f"out_{device}_{i}", out_bytes, device)
                 regions += [hin, hout]
-                pre(images, hin)  # HIP kernel writes the batch straight into the region
+                if tiled is not None:
+                    hipshm.set_shared_memory_region_from_dlpack(hin, [tiled])
+                else:
+                    pre(images, hin)  # HIP kernel writes the batch straight into the region
                 control.register_cuda_shared_memory(f"in_{device}_{i}", hipshm.get_raw_handle(hin), device, in_bytes)
                 control.register_cuda_shared_memory(f"out_{device}_{i}", hipshm.get_raw_handle(hout), device, out_bytes)
                 cleanup.append(lambda i=i: (control.unregister_cuda_shared_memory(f"in_{device}_{i}"),
@@ -131,7 +152,7 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
             x = torch.empty(b, 3, 224, 224, device=f"cuda:{device}", dtype=torch.float16)
             pre(images, x)
             host = x.cpu().numpy()
-            for i in range(args.concurrency):
+            for i in range(concurrency):
                 kin, kout = f"/tca_b_in_{os.getpid()}_{i}", f"/tca_b_out_{os.getpid()}_{i}"
                 hin = sysshm.create_shared_memory_region(f"in_{device}_{i}", kin, in_bytes)
                 hout = sysshm.create_shared_memory_region(f"out_{device}_{i}", kout, out_bytes)
@@ -363,6 +384,52 @@ def measure(args, url, device, dist, label):
     }
 
 
+def measure_fanout(args, world):
+    """``resnet50_sharded`` on GPU 0 with one replica process per further GPU: requests of
+    ``32 x replicas`` images in HIP shared memory, split over the replicas and gathered into
+    the caller's output region.  One run per transport (peer stores + device flags, RCCL
+    point-to-point).  A failure is reported in the result, it does not fail the benchmark."""
+    import torch
+
+    from triton_client_amd.server import spawn_server
+
+    if args.fanout_devices is not None:
+        devices = [int(v) for v in args.fanout_devices.split(",") if v.strip() != ""]
+    else:
+        devices = list(range(1, world)) if world > 1 else [0, 0]
+    replicas = 1 + len(devices)
+    same_gpu = len(set(devices + [0])) < replicas
+    batch = 32 * replicas
+    out = {"replicas": replicas, "devices": [0] + devices, "batch_per_request": batch, "concurrency": 8,
+           "note": "replicas share one GPU (rehearsal)" if same_gpu else "one replica per GPU"}
+    for mode in [m for m in args.fanout_modes.split(",") if m]:
+        if mode == "rccl" and same_gpu:
+            out[mode] = {"skipped": "RCCL needs one GPU per rank"}
+            continue
+        server = None
+        try:
+            t0 = time.perf_counter()
+            server = spawn_server(models=["resnet50_sharded"], gpu=0, startup_timeout=900,
+                                  env={"TCA_SHARD_DEVICES": ",".join(str(d) for d in devices), "TCA_SHARD_MODE": mode},
+                                  extra_args=["--grpc-workers", "32"])
+            start_s = time.perf_counter() - t0
+            args.control_url = server.grpc_url
+            url = server.grpc_url if args.protocol == "grpc" else server.http_url
+            r = measure_native(args, url, 0, None, f"fanout-{mode}", mode="hip", steps=1,
+                               per_step=args.fanout_requests, warmup_requests=64, model="resnet50_sharded",
+                               batch=batch, concurrency=8)
+            out[mode] = {"infer_per_sec": round(r["infer_per_sec"], 1), "p50_latency_us": round(r["p50_us"], 1),
+                         "p99_latency_us": round(r["p99_us"], 1), "requests": r["requests"],
+                         "elapsed_s": round(r["elapsed_s"], 4), "startup_s": round(start_s, 1)}
+        except BaseException as e:  # noqa: BLE001 - the headline number must survive
+            out[mode] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        finally:
+            if server is not None:
+                server.stop(timeout=40)
+            torch.cuda.synchronize()
+    return out
+
+
 def launch_ranks(args):
     """``--gpus N`` without a launcher: start the N ranks as children of this
     process, which has not touched the GPU and only relays.  Rank 0's JSON line
@@ -447,6 +514,23 @@ def main():
         server.stop()
     if dist is not None:
         dist.barrier()
+    if not args.no_extras and args.client == "native" and (args.mode == "fanout" or world > 1):
+        # every rank's server is down; rank 0 serves resnet50_sharded with one replica per GPU
+        # the other ranks wait on the host (a collective barrier would spin on their GPUs,
+        # which are the replicas' GPUs now)
+        store = None
+        if dist is not None:
+            from datetime import timedelta
+
+            store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            try:
+                extras["fanout"] = measure_fanout(args, world)
+            finally:
+                if store is not None:
+                    store.set("tca_fanout_done", "1")
+        elif store is not None:
+            store.wait(["tca_fanout_done"], timedelta(minutes=40))
     if rank == 0:
         n = world
         ms_per_step = main_result["elapsed_s"] * 1e3 / args.steps

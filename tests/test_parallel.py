@@ -21,7 +21,7 @@ def _worker(rank, world, port, mode, batch, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from triton_client_amd.parallel import BatchFanout, ShardedModelGroup
+        from triton_client_amd.parallel import BatchFanout
 
         fan = BatchFanout(root=0, mode=mode)
         full = torch.arange(batch * 6, dtype=torch.float32).reshape(batch, 2, 3) if rank == 0 else None
@@ -43,17 +43,6 @@ def _worker(rank, world, port, mode, batch, q):
         assert (rooted is None) == (rank != 0)
         if rank == 0:
             assert torch.equal(rooted, ref)
-        # sharded model group: root drives two steps then stops the others
-        group = ShardedModelGroup(lambda x: x.reshape(x.shape[0], -1).sum(dim=1, keepdim=True), (2, 3),
-                                  torch.float32, "cpu", root=0, mode=mode)
-        if rank == 0:
-            for b in (batch, batch * 2):
-                data = torch.ones(b, 2, 3)
-                out = group.step(data)
-                assert torch.equal(out, torch.full((b, 1), 6.0))
-            group.stop()
-        else:
-            group.serve()
         q.put((rank, "ok"))
     except Exception as e:  # report instead of hanging the peers
         q.put((rank, f"{type(e).__name__}: {e}"))
@@ -106,88 +95,6 @@ def test_sharded_client_failover():
             b.stop()
         except Exception:
             pass
-
-
-def _direct_worker(rank, world, port, batch, device, q):
-    """Scatter / gather through peer-mapped buffers.  ``device`` None = host-backed
-    regions (CPU); otherwise every rank uses that GPU (IPC between processes)."""
-    import torch
-    import torch.distributed as dist
-
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    if device is None:
-        os.environ["TCA_HIPSHM_FAKE"] = "1"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from triton_client_amd.parallel import DirectPeerExchange
-
-        dev = "cpu" if device is None else f"cuda:{device}"
-        ex = DirectPeerExchange(shard_bytes=batch * 6 * 2, out_bytes=batch * 4 * 4, device=device or 0, root=0)
-        for step in range(3):  # buffers are reused across steps
-            full = None
-            ref = (torch.arange(batch * 6, dtype=torch.float32).reshape(batch, 2, 3) + step).half()
-            if rank == 0:
-                full = ref.to(dev)
-            shard = ex.scatter(full, (batch, 2, 3), torch.float16)
-            sizes = ex.shard_sizes(batch)
-            start = sum(sizes[:rank])
-            assert torch.equal(shard.cpu(), ref[start:start + sizes[rank]]), (rank, step)
-            local = shard.float().reshape(shard.shape[0], -1).sum(dim=1, keepdim=True).repeat(1, 4) + rank * 1000
-            out = ex.gather(local, batch)
-            assert (out is None) == (rank != 0)
-            if rank == 0:
-                rows = []
-                for r, n in enumerate(sizes):
-                    s0 = sum(sizes[:r])
-                    rows.append(ref[s0:s0 + n].float().reshape(n, -1).sum(dim=1, keepdim=True).repeat(1, 4) + r * 1000)
-                assert torch.equal(out.cpu(), torch.cat(rows)), step
-        ex.close()
-        # the same transport behind ShardedModelGroup
-        from triton_client_amd.parallel import ShardedModelGroup
-
-        grp = ShardedModelGroup(lambda x: x.float().reshape(x.shape[0], -1).sum(dim=1, keepdim=True), (2, 3),
-                                torch.float16, dev, root=0, mode="direct", max_batch=32, out_row_bytes=4)
-        if rank == 0:
-            out = grp.step(torch.ones(batch, 2, 3, dtype=torch.float16, device=dev))
-            assert torch.equal(out.cpu(), torch.full((batch, 1), 6.0))
-            grp.stop()
-        else:
-            grp.serve()
-        grp.close()
-        q.put((rank, "ok"))
-    except Exception as e:
-        import traceback
-
-        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
-    finally:
-        dist.destroy_process_group()
-
-
-def _run_direct(world, batch, device):
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, batch, device, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=30)
-    assert sorted(results) == [(r, "ok") for r in range(world)], results
-
-
-@pytest.mark.parametrize("world,batch", [(2, 8), (3, 8), (2, 5)])
-def test_direct_peer_exchange_host_backed(world, batch):
-    _run_direct(world, batch, None)
-
-
-@pytest.mark.gpu
-def test_direct_peer_exchange_hip_ipc():
-    """Real hipIpc mappings and device-to-device copies: three ranks sharing GPU 0."""
-    _run_direct(3, 16, 0)
 
 
 def test_sharded_client_sequences_and_streams():

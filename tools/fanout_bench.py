@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Fan-out / gather of a batched request over N GPUs: RCCL scatter + all_gather
-against plain peer-mapped copies (one stream per xGMI link).
+"""Transport cost of the sharded group: a batch of fp16 images leaves the ingest GPU for N-1
+replica processes and fp32 logit rows come back, with replicas that compute nothing.
 
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-      tools/fanout_bench.py --batch 256
+  python tools/fanout_bench.py --gpus 8 --batch 256            # one replica per GPU
+  python tools/fanout_bench.py --devices 0,0 --batch 96        # rehearsal: three replicas on GPU 0
 
-Prints, on rank 0, the time per step and the bytes/s leaving the ingest GPU for
-both transports.  One rank per GPU; needs at least two GPUs."""
+Prints one JSON line per transport ("direct": peer stores + device flags, "rccl": point-to-
+point operations of torch.distributed) with the time per step, the bytes per second that
+leave the ingest GPU and that figure per xGMI link (one link per peer)."""
 import argparse
 import json
 import os
@@ -14,62 +15,70 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None, help="replicas = GPUs 0..N-1")
+    ap.add_argument("--devices", default=None, help="GPU ordinals of the replicas besides GPU 0")
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--modes", default="direct,rccl")
+    ap.add_argument("--flags", default=None, choices=[None, "kernel", "stream"])
     args = ap.parse_args()
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world < 2:
-        raise SystemExit("launch with torchrun on at least two GPUs")
-    torch.cuda.set_device(local)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    from triton_client_amd.parallel import BatchFanout, DirectPeerExchange
+    from triton_client_amd.parallel.sharded import SLOTS, ShardRoot
 
-    dev = torch.device("cuda", local)
-    shape = (args.batch, 3, 224, 224)
-    full = torch.randn(*shape, device=dev).half() if rank == 0 else None
-    rows = -(-args.batch // world)
-    fan = BatchFanout(root=0, mode="scatter")
-    ex = DirectPeerExchange(rows * 3 * 224 * 224 * 2, rows * 1000 * 4, device=local, root=0)
-    out_rows = torch.zeros(fan.shard_sizes(args.batch)[rank], 1000, device=dev)
+    if args.devices is not None:
+        devices = [int(v) for v in args.devices.split(",") if v.strip() != ""]
+    else:
+        devices = list(range(1, args.gpus or torch.cuda.device_count()))
+    if not devices:
+        raise SystemExit("needs at least one replica besides GPU 0 (--gpus N or --devices)")
+    world = 1 + len(devices)
+    same_gpu = len(set(devices + [0])) < world
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sample_bytes, out_row_bytes = 3 * 224 * 224 * 2, 1000 * 4
+    x = torch.randn(args.batch, 3, 224, 224, device=dev).half()
+    out = torch.zeros(args.batch, 1000, device=dev)
+    for mode in [m for m in args.modes.split(",") if m]:
+        if mode == "rccl" and same_gpu:
+            print(json.dumps({"mode": mode, "skipped": "RCCL needs one GPU per rank"}))
+            continue
+        streams = [torch.cuda.Stream(device=dev) for _ in range(SLOTS)]
+        root = ShardRoot(lambda a, b, slot: None, world, 0, sample_bytes, out_row_bytes, args.batch, streams=streams,
+                         mode=mode, flags=args.flags, timeout_ms=20000)
+        try:
+            root.spawn_workers(devices, model="test_noop", startup_timeout=300.0)
 
-    def timed(fn):
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.iters):
-            fn()
-        torch.cuda.synchronize()
-        dist.barrier()
-        return (time.perf_counter() - t0) / args.iters
+            def run(n):
+                for i in range(n):
+                    root.step(x, out, i % SLOTS)
+                for s in streams:
+                    s.synchronize()
 
-    def rccl():
-        fan.fan_out(full, shape, torch.float16, dev)
-        fan.gather_to_root(out_rows, args.batch)
-
-    def direct():
-        ex.scatter(full, shape, torch.float16)
-        ex.gather(out_rows, args.batch)
-
-    t_rccl, t_direct = timed(rccl), timed(direct)
-    sent = (args.batch - fan.shard_sizes(args.batch)[0]) * 3 * 224 * 224 * 2  # bytes that leave the root
-    if rank == 0:
-        print(json.dumps({"gpus": world, "batch": args.batch, "rccl_ms": round(t_rccl * 1e3, 3),
-                          "direct_ms": round(t_direct * 1e3, 3), "rccl_GBps_out": round(sent / t_rccl / 1e9, 1),
-                          "direct_GBps_out": round(sent / t_direct / 1e9, 1)}))
-    ex.close()
-    dist.destroy_process_group()
+            run(20)
+            t0 = time.perf_counter()
+            run(args.iters)
+            dt = (time.perf_counter() - t0) / args.iters
+            # latency of one isolated step (nothing else in flight)
+            lat = []
+            for _ in range(20):
+                t1 = time.perf_counter()
+                run(1)
+                lat.append(time.perf_counter() - t1)
+            root.check()
+        finally:
+            root.close()
+        sent = (args.batch - -(-args.batch // world)) * sample_bytes  # bytes that leave the ingest GPU per step
+        print(json.dumps({"mode": mode, "replicas": world, "devices": [0] + devices, "same_gpu": same_gpu,
+                          "batch": args.batch, "us_per_step_pipelined": round(dt * 1e6, 1),
+                          "us_per_step_isolated_p50": round(sorted(lat)[len(lat) // 2] * 1e6, 1),
+                          "GBps_out_of_root": round(sent / dt / 1e9, 1),
+                          "GBps_per_link": round(sent / dt / 1e9 / len(devices), 1)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ link per direction per GPU, so:
 
 Messages are exchanged as ONE contiguous tensor per call (no per-sample
 collectives); callers that stream many small requests should coalesce them
-first (``ShardedModelGroup`` does).  Works on any ``torch.distributed`` backend:
+first (the server's dynamic batcher does).  Works on any ``torch.distributed`` backend:
 "nccl" (RCCL) on GPUs, "gloo" on CPUs for tests.
 """
 

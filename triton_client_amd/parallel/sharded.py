@@ -297,7 +297,8 @@ class ShardRoot:
         if env:
             child_env.update(env)
         for rank, dev in enumerate(devices, start=1):
-            cmd = [sys.executable, "-u", "-m", "triton_client_amd.parallel.sharded", "--rank", str(rank), "--device",
+            cmd = [sys.executable, "-u", "-c", "from triton_client_amd.parallel.sharded import main; main()",
+                   "--rank", str(rank), "--device",
                    str(dev), "--address", f"{address[0]}:{address[1]}", "--model", model, "--warm-rows",
                    ",".join(str(r) for r in warm_rows), "--shard-rows", str(self.shard_rows), "--sample-shape",
                    ",".join(str(v) for v in sample_shape), "--out-shape", ",".join(str(v) for v in out_shape)]
@@ -721,6 +722,16 @@ def _rowsum_forward_factory(worker):
     return forward, streams
 
 
+def _noop_forward_factory(worker):
+    """Replica that computes nothing (``out`` keeps what it held): transport measurements."""
+    streams = None
+    if not worker.fake:
+        import torch
+
+        streams = [torch.cuda.Stream(device=worker.device) for _ in range(SLOTS)]
+    return (lambda x, out, slot: None), streams
+
+
 def main(argv=None):
     import argparse
 
@@ -728,7 +739,7 @@ def main(argv=None):
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--device", type=int, required=True)
     ap.add_argument("--address", required=True)
-    ap.add_argument("--model", default="resnet50", help="zoo model, or 'test_rowsum' (stand-in used by the tests)")
+    ap.add_argument("--model", default="resnet50", help="zoo model, or the stand-ins 'test_rowsum' (tests) / 'test_noop' (transport benchmark)")
     ap.add_argument("--warm-rows", default="")
     ap.add_argument("--shard-rows", type=int, default=int(os.environ.get("TCA_SHARD_ROWS", "128")))
     ap.add_argument("--sample-shape", default="3,224,224")
@@ -739,7 +750,9 @@ def main(argv=None):
     authkey = bytes.fromhex(os.environ["TCA_SHARD_AUTHKEY"])
     sample_shape = tuple(int(v) for v in args.sample_shape.split(","))
     out_shape = tuple(int(v) for v in args.out_shape.split(","))
-    factory = _rowsum_forward_factory if args.model == "test_rowsum" else _resnet_forward_factory(args.model)
+    factory = {"test_rowsum": _rowsum_forward_factory, "test_noop": _noop_forward_factory}.get(args.model)
+    if factory is None:
+        factory = _resnet_forward_factory(args.model)
     worker = ShardWorker(args.rank, args.device, (host, int(port)), authkey, factory, sample_shape=sample_shape,
                          out_shape=out_shape)
     try:
