@@ -70,12 +70,39 @@ struct RowMap {  // output pixel index -> input pixel(s)
   int cin;
 };
 
+// n / d for 0 <= n < 2^24 and d >= 7 (pixel indices by image / row sizes): a float estimate and two
+// fix-ups, about ten vector instructions where the compiler's exact 32-bit division takes forty.
+// The estimate is off by at most one: float(n) is exact, the quotient stays below 2^22.
+__device__ __forceinline__ int SmallDiv(int n, int d, float inv_d) {
+  int q = static_cast<int>(static_cast<float>(n) * inv_d);
+  int r = n - q * d;
+  if (r < 0) {
+    --q;
+    r += d;
+  }
+  if (r >= d) ++q;
+  return q;
+}
+
+// (m / ohw, (m % ohw) / ow, (m % ohw) % ow)
+__device__ __forceinline__ void SplitPixel(const RowMap& map, int m, bool small, int& img, int& oh, int& ow) {
+  if (small) {
+    img = SmallDiv(m, map.ohw, 1.0f / static_cast<float>(map.ohw));
+    const int rem = m - img * map.ohw;
+    oh = SmallDiv(rem, map.ow, 1.0f / static_cast<float>(map.ow));
+    ow = rem - oh * map.ow;
+  } else {
+    img = m / map.ohw;
+    const int rem = m - img * map.ohw;
+    oh = rem / map.ow;
+    ow = rem - oh * map.ow;
+  }
+}
+
 __device__ __forceinline__ long long InRow(const RowMap& map, int m) {
   if (map.identity) return m;
-  const int img = m / map.ohw;
-  const int rem = m - img * map.ohw;
-  const int oh = rem / map.ow;
-  const int ow = rem - oh * map.ow;
+  int img, oh, ow;
+  SplitPixel(map, m, m < (1 << 24) && map.ow >= 7, img, oh, ow);
   return static_cast<long long>(img) * map.in_h * map.in_w + static_cast<long long>(oh) * map.stride * map.in_w +
          ow * map.stride;
 }
@@ -99,6 +126,15 @@ __device__ __forceinline__ void DmaToLds(__amdgpu_buffer_rsrc_t rsrc, unsigned v
                                            static_cast<int>(voffset), soffset, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only: this wave's LDS reads / writes have completed, vector
+// memory operations (LDS DMA, loads, output stores) stay in flight across it.  __syncthreads() would wait
+// for every one of them - store acknowledgements included - because a pending LDS DMA counts as an
+// LDS write it has to fence.
+__device__ __forceinline__ void LdsBarrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // Second, back-to-back GEMM of the fused form (kFuse): the convolution's output tile never
 // leaves the CU - it is multiplied by a 1x1 convolution's weights straight from LDS.
 struct Pointwise2 {
@@ -118,8 +154,8 @@ struct Pointwise3 {
   _Float16* out;         // [M][kN3] = relu(y x w^T + bias)
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0>
-__global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0, bool kHalo = false>
+__global__ __launch_bounds__(128 * kWN, kFuse ? kWN : 1) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias,
                                                           const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ Y, int M, int N, int K, int relu,
@@ -133,7 +169,13 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
   constexpr int kMI = BM / 32;               // 16-wide fragments per wave along m
   constexpr int kNI = BN / (16 * kWN);       // along n
   static_assert(kAVecs >= 1 && kWVecs >= 1 && kNI >= 1, "tile too small for the wave layout");
-  constexpr int kStageHalfs = (BM + BN) * kBK;
+  // kHalo (3x3, stride 1, pad 1): the activation rows a tile's nine taps touch - the tile's own pixels plus
+  // one image row and one pixel on either side, as consecutive rows of the flattened [pixels][cin] input -
+  // are brought into LDS ONCE; tap (kh, kw) of output pixel m reads halo row m + kh*W + kw.  The K loop then
+  // only streams weights.  Instead of nine activation tiles per block from L2 (and nine round trips) it is
+  // one, 1.9x the tile at 128 pixels of a 56-wide image.
+  static_assert(!kHalo || (kSpatial && kGlds), "the halo form is the DMA-staged implicit GEMM");
+  constexpr int kStageHalfs = kHalo ? BN * kBK : (BM + BN) * kBK;
   constexpr int kCPitch = BN + 8;  // halfs; 16-byte aligned rows, spreads the transposed stores over banks
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
 
@@ -161,21 +203,44 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
   // test and a select per activation vector and nothing per weight vector; the step's
   // tap / channel displacement is wave-uniform and rides in the scalar offset.
   unsigned a_off[kAVecs], a_taps[kAVecs], w_off[kWVecs];
+  // halo form: LDS rows of the halo, validity bits of the nine taps per fragment row, the operand stages behind it
+  const int halo_rows = kHalo ? ((BM + 2 * map.in_w + 2) / (8 * kW) + 1) * (8 * kW) : 0;  // >= 1 spare row: reads as zeros
+  _Float16* const stage0 = lds + (kHalo ? (map.cin / kBK) * halo_rows * kBK : 0);
+  unsigned h_taps[kMI];
+  const bool small_pixels = M + BM < (1 << 24) && map.ow >= 7;  // wave-uniform: the cheap pixel-index division applies
   // elements the activation descriptor's base sits BEFORE X, so the offset of the
   // (possibly negative) top-left tap coordinate is never negative
   const int lead = kSpatial ? (map.pad * map.in_w + map.pad) * map.cin : 0;
+  if constexpr (kHalo) {
+#pragma unroll
+    for (int mi = 0; mi < kMI; ++mi) {
+      const int m = m0 + wm * (BM / 2) + mi * 16 + (lane & 15);
+      int img, oh, ow;
+      SplitPixel(map, m, small_pixels, img, oh, ow);
+      unsigned rows_ok = 0, cols_ok = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        rows_ok |= static_cast<unsigned>(static_cast<unsigned>(oh - 1 + k) < static_cast<unsigned>(map.in_h)) << k;
+        cols_ok |= static_cast<unsigned>(static_cast<unsigned>(ow - 1 + k) < static_cast<unsigned>(map.in_w)) << k;
+      }
+      unsigned taps = 0;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+        if ((rows_ok >> kh) & 1u) taps |= cols_ok << (kh * 3);
+      h_taps[mi] = m < M ? taps : 0u;
+    }
+  }
   if constexpr (kGlds) {
 #pragma unroll
     for (int i = 0; i < kAVecs; ++i) {
+      if constexpr (kHalo) break;
       const int v = (i * kW + wave) * 64 + lane;
       const int row = v >> 3;
       const int chunk = (v & 7) ^ ((row >> 1) & 7);
       const int m = m0 + row;
       if constexpr (kSpatial) {
-        const int img = m / map.ohw;
-        const int rem = m - img * map.ohw;
-        const int oh = rem / map.ow;
-        const int ow = rem - oh * map.ow;
+        int img, oh, ow;
+        SplitPixel(map, m, small_pixels, img, oh, ow);
         const int ih0 = oh * map.stride - map.pad;
         const int iw0 = ow * map.stride - map.pad;
         const long long pixel = (static_cast<long long>(img) * map.in_h + ih0) * map.in_w + iw0;
@@ -223,13 +288,15 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     next_kw = next_tap - next_kh * map.ksize;
   }
   auto issue_tile = [&](int stage) {
-    _Float16* base = lds + stage * kStageHalfs;
+    _Float16* base = stage0 + stage * kStageHalfs;
     if constexpr (kSpatial) {
-      const int soff = ((next_kh * map.in_w + next_kw) * map.cin + next_c0) * 2;
-      const unsigned bit = 1u << next_tap;
+      if constexpr (!kHalo) {
+        const int soff = ((next_kh * map.in_w + next_kw) * map.cin + next_c0) * 2;
+        const unsigned bit = 1u << next_tap;
 #pragma unroll
-      for (int i = 0; i < kAVecs; ++i)
-        DmaToLds(x_rsrc, (a_taps[i] & bit) ? a_off[i] : kOutOfRange, soff, base + (i * kW + wave) * 512);
+        for (int i = 0; i < kAVecs; ++i)
+          DmaToLds(x_rsrc, (a_taps[i] & bit) ? a_off[i] : kOutOfRange, soff, base + (i * kW + wave) * 512);
+      }
       next_c0 += kBK;
       if (next_c0 == map.cin) {
         next_c0 = 0;
@@ -244,8 +311,26 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
       for (int i = 0; i < kAVecs; ++i) DmaToLds(x_rsrc, a_off[i], next_k0 * 2, base + (i * kW + wave) * 512);
     }
 #pragma unroll
-    for (int i = 0; i < kWVecs; ++i) DmaToLds(w_rsrc, w_off[i], next_k0 * 2, base + BM * kBK + (i * kW + wave) * 512);
+    for (int i = 0; i < kWVecs; ++i)
+      DmaToLds(w_rsrc, w_off[i], next_k0 * 2, base + (kHalo ? 0 : BM * kBK) + (i * kW + wave) * 512);
     next_k0 += kBK;
+  };
+  // the halo: wave instruction j fills LDS rows 8j .. 8j+7 of a 64-channel slice (lane l: row 8j + l/8, the
+  // 16-byte chunk whose place l%8 is under the halo's swizzle, chunk ^ (row & 7): conflict-free fragment
+  // reads at every row shift); rows outside the tensor, and the spare rows, get zeros from the range check
+  auto issue_halo = [&]() {
+    const int slices = map.cin / kBK;
+    const int first = m0 - map.in_w - 1;  // flattened input pixel of halo row 0
+    const long long pixels = static_cast<long long>(M);  // stride 1, pad 1: as many input as output pixels
+    for (int sl = 0; sl < slices; ++sl)
+      for (int j = wave; j < halo_rows / 8; j += kW) {
+        const int row = j * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        const long long p = static_cast<long long>(first) + row;
+        const bool ok = p >= 0 && p < pixels && row < BM + 2 * map.in_w + 2;
+        DmaToLds(x_rsrc, ok ? static_cast<unsigned>((p * map.cin + lead + sl * kBK + chunk * 8) * 2) : kOutOfRange, 0,
+                 lds + (sl * halo_rows + j * 8) * kBK);
+      }
   };
 
   // ---- register staging (global -> VGPR -> LDS): the A/B alternative ---------------
@@ -334,8 +419,48 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
   const int frag_chunk = (lane >> 4) ^ ((frag_row >> 1) & 7);
   const int xf_off = (wm * (BM / 2) + frag_row) * kBK + frag_chunk * 8;
   const int wf_off = BM * kBK + (wn * (BN / kWN) + frag_row) * kBK + frag_chunk * 8;
+  // halo form: position of the K step being computed
+  int cur_c0 = 0, cur_tap = 0, cur_toff = 0, cur_kw = 0;
+  const int h_row = wm * (BM / 2) + (lane & 15);
   auto compute_tile = [&](int stage) {
-    const _Float16* base = lds + stage * kStageHalfs;
+    const _Float16* base = stage0 + stage * kStageHalfs;
+    if constexpr (kHalo) {
+      const _Float16* slice = lds + (cur_c0 / kBK) * halo_rows * kBK;
+      const unsigned bit = 1u << cur_tap;
+      // a tap outside the image reads the spare (zero) row
+      const int zero_off = (BM + 2 * map.in_w + 2) * kBK + (lane >> 4) * 8;
+      // rows 16 apart share the swizzle term (row & 7): one address, then constant steps
+      const int hr0 = h_row + cur_toff;
+      const int off0 = hr0 * kBK + (((lane >> 4) ^ hr0) & 7) * 8;
+      int x_off[kMI];
+#pragma unroll
+      for (int mi = 0; mi < kMI; ++mi) x_off[mi] = (h_taps[mi] & bit) ? off0 + mi * 16 * kBK : zero_off;
+      const int w_off2 = (wn * (BN / kWN) + frag_row) * kBK + frag_chunk * 8;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        half8 xf[kMI], wf[kNI];
+#pragma unroll
+        for (int mi = 0; mi < kMI; ++mi) xf[mi] = *reinterpret_cast<const half8*>(slice + (x_off[mi] ^ (kk * 32)));
+#pragma unroll
+        for (int ni = 0; ni < kNI; ++ni) wf[ni] = *reinterpret_cast<const half8*>(base + ((w_off2 ^ (kk * 32)) + ni * 16 * kBK));
+#pragma unroll
+        for (int ni = 0; ni < kNI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < kMI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+      }
+      cur_c0 += kBK;
+      if (cur_c0 == map.cin) {
+        cur_c0 = 0;
+        ++cur_tap;
+        ++cur_toff;
+        if (++cur_kw == 3) {
+          cur_kw = 0;
+          cur_toff += map.in_w - 3;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const _Float16* xs = base + (xf_off ^ (kk * 32));
@@ -353,18 +478,110 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     }
   };
 
+  // ---- fused form: everything the second / third GEMM will need first, requested before the K loop ----
+  // Plain register loads (no LDS DMA in the fused phase): they complete in issue order beside the K loop's
+  // DMA and are long there when the loop ends, and the compiler's counted waits see all of them.
+  using uint4v = __attribute__((ext_vector_type(4))) unsigned;
+  constexpr int kSlabs = kFuse ? BN / kBK + kXS : 1;  // K steps of the second GEMM: the first result's channels (+ the extra operand's)
+  constexpr int kBN2 = 64;
+  constexpr int kNI2 = kFuse ? kBN2 / (16 * kWN) : 1;
+  constexpr int kW2Vecs = kFuse ? kBN2 * 8 * kSlabs / kT : 1;
+  constexpr int kNI3 = kN3 > 0 ? kN3 / (16 * kWN) : 1;
+  constexpr int kW3Vecs = kN3 > 0 ? kN3 * 8 / kT : 1;
+  constexpr int kRowVecs2 = kBN2 / 8;
+  constexpr int kOutVecs2 = kFuse ? BM * kRowVecs2 / kT : 1;
+  static_assert(!kFuse || (kNI2 >= 1 && BN % kBK == 0 && kW2Vecs >= 1 && kOutVecs2 >= 1),
+                "wave layout too wide for the 64-channel chunks of the fused GEMM");
+  static_assert(kN3 == 0 || (kN3 % (16 * kWN) == 0 && kN3 * 8 % kT == 0), "third GEMM: channel count does not fit the wave layout");
+  const int N2 = pw2.n;
+  unsigned w2_off[kW2Vecs], w3_off[kW3Vecs];
+  uint4v w2r[kW2Vecs], w3r[kW3Vecs];  // the next weight chunks, on their way to LDS
+  half8 res_r[kOutVecs2];            // residual rows of the next chunk
+  half4 b1r[kNI], b2r[kNI2], b3r[kNI3];
+  __amdgpu_buffer_rsrc_t w2_rsrc = w_rsrc, w3_rsrc = w_rsrc;
+  auto load_w2 = [&](int chunk_index) {
+#pragma unroll
+    for (int i = 0; i < kW2Vecs; ++i)
+      w2r[i] = __builtin_amdgcn_raw_buffer_load_b128(w2_rsrc, static_cast<int>(w2_off[i]),
+                                                     chunk_index * kBN2 * (kSlabs * kBK) * 2, 0);
+  };
+  auto load_w3 = [&](int chunk_index) {
+#pragma unroll
+    for (int i = 0; i < kW3Vecs; ++i)
+      w3r[i] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, static_cast<int>(w3_off[i]), chunk_index * kBN2 * 2, 0);
+  };
+  auto load_res = [&](int chunk_index) {  // rows past M: the last row, unused
+#pragma unroll
+    for (int i = 0; i < kOutVecs2; ++i) {
+      const int v = tid + i * kT;
+      const int row = v / kRowVecs2;
+      const int cv = v - row * kRowVecs2;
+      const int m = m0 + row < M ? m0 + row : M - 1;
+      res_r[i] = *reinterpret_cast<const half8*>(residual + static_cast<long long>(m) * N2 + chunk_index * kBN2 + cv * 8);
+    }
+  };
+  auto load_bias2 = [&](int chunk_index) {
+#pragma unroll
+    for (int ni = 0; ni < kNI2; ++ni)
+      b2r[ni] = *reinterpret_cast<const half4*>(pw2.bias + chunk_index * kBN2 + wn * (kBN2 / kWN) + ni * 16 + (lane >> 4) * 4);
+  };
+  // With the 128x128 first tile the K loop has no registers to spare for them (it would cost a block per
+  // CU): that form asks right after the K loop instead.
+  constexpr bool kEarlyPrefetch = BM * BN < 128 * 128;
+  auto prefetch_first = [&]() {
+    w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw2.w), 0, N2 * (kSlabs * kBK) * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < kW2Vecs; ++i) {
+      const int v = (i * kW + wave) * 64 + lane;
+      const int slab = v >> 9;  // 512 vectors (64 rows x 8 chunks) per slab
+      const int row = (v & 511) >> 3;
+      const int chunk = (v & 7) ^ ((row >> 1) & 7);
+      w2_off[i] = static_cast<unsigned>((row * (kSlabs * kBK) + slab * kBK + chunk * 8) * 2);
+    }
+    load_w2(0);
+    if constexpr (kN3 > 0) {
+      w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw3.w), 0, kN3 * N2 * 2, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < kW3Vecs; ++i) {
+        const int v = (i * kW + wave) * 64 + lane;
+        const int row = v >> 3;
+        const int chunk = (v & 7) ^ ((row >> 1) & 7);
+        w3_off[i] = static_cast<unsigned>((row * N2 + chunk * 8) * 2);
+      }
+      load_w3(0);
+#pragma unroll
+      for (int ni = 0; ni < kNI3; ++ni)
+        b3r[ni] = pw3.bias != nullptr
+                      ? *reinterpret_cast<const half4*>(pw3.bias + wn * (kN3 / kWN) + ni * 16 + (lane >> 4) * 4)
+                      : half4{0, 0, 0, 0};
+    }
+    if (residual != nullptr) load_res(0);
+    if (pw2.bias != nullptr) load_bias2(0);
+#pragma unroll
+    for (int ni = 0; ni < kNI; ++ni)
+      b1r[ni] = bias != nullptr ? *reinterpret_cast<const half4*>(bias + wn * (BN / kWN) + ni * 16 + (lane >> 4) * 4)
+                                : half4{0, 0, 0, 0};
+  };
+  if constexpr (kFuse && kEarlyPrefetch) prefetch_first();
+
   if constexpr (kGlds) {
     // `stages` LDS stages, the DMA runs stages-1 K steps ahead.  Per step: wait until
     // THIS step's DMA has landed (with three stages a counted vmcnt leaves the next
     // step's loads in flight), one raw barrier (a plain __syncthreads() would drain the
     // DMA queue), then refill the stage every wave finished reading one step ago.
-    constexpr int kPerTile = kAVecs + kWVecs;  // DMA instructions a thread issues per K step
+    constexpr int kPerTile = kHalo ? kWVecs : kAVecs + kWVecs;  // DMA instructions a thread issues per K step
     const int ahead = stages > 1 ? stages - 1 : 1;
+    if constexpr (kHalo) issue_halo();  // older than every weight tile: landed when the first of them has
     for (int p = 0; p < ahead && p < ktiles; ++p) issue_tile(p);
     int stage = 0;
     int refill = stages > 1 ? ahead : 0;
     for (int kt = 0; kt < ktiles; ++kt) {
-      if (ahead == 2 && kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerTile) : "memory");
+      // K steps issued beyond this one (they may stay in flight: loads complete in issue order)
+      const int issued = kt + ahead < ktiles ? kt + ahead : ktiles;
+      const int beyond = issued - (kt + 1);
+      if (beyond >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kPerTile) : "memory");
+      else if (beyond == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPerTile) : "memory");
+      else if (beyond == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerTile) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (kt + ahead < ktiles) {
@@ -456,21 +673,19 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
   }
 
   if constexpr (kFuse) {
+    if constexpr (!kEarlyPrefetch) prefetch_first();
     // ---- fused 1x1 convolution: Y = act(relu(conv + bias) x W2^T + bias2 (+ residual)) ----
     // The first result tile [BM pixels][BN channels] (BN = all of its channels: tiles_n == 1)
     // goes to LDS in the operand layout of the K loop above - one [BM][64] swizzled slab per
     // 64 channels - and serves as the activation operand of a second GEMM whose K is BN.
-    // Its weights arrive by the same DMA, 64 output channels at a time, into ONE buffer that
-    // is refilled while the previous chunk's epilogue stores run (a second buffer would push
-    // the 128-channel form past the LDS budget of two blocks per CU); every 64-channel chunk
-    // runs the usual transposing epilogue.  The intermediate
-    // activation is never written to memory and never read back.
-    constexpr int kSlabs = BN / kBK + kXS;  // K steps of the second GEMM: the first result's channels (+ the extra operand's)
-    constexpr int kBN2 = 64;
-    constexpr int kNI2 = kBN2 / (16 * kWN);
-    static_assert(kNI2 >= 1 && BN % kBK == 0, "wave layout too wide for the 64-channel chunks of the fused GEMM");
-    constexpr int kW2Vecs = kBN2 * 8 * kSlabs / kT;
-    static_assert(kW2Vecs >= 1, "fused GEMM: fewer weight vectors than threads");
+    // Its weights come 64 output channels at a time: each chunk is loaded into registers one
+    // chunk early and written to ONE LDS buffer as soon as the previous chunk's MFMAs are done
+    // with it (a second buffer would push the 128-channel form past the LDS budget of two
+    // blocks per CU); every 64-channel chunk runs the usual transposing epilogue.  The
+    // intermediate activation is never written to memory and never read back.  Nothing in the
+    // chunk loop waits for a memory round trip it has just started: weights, residual rows and
+    // biases of chunk c + 1 are requested while chunk c computes, the output stores are never
+    // waited for (the barriers only order LDS traffic).
     _Float16* ts = lds;                              // [kSlabs][BM][kBK]
     _Float16* w2s = lds + BM * kBK * kSlabs;         // [kSlabs][kBN2][kBK]
     // [BM][kBK] in the operand-slab layout (128-byte rows, 16-byte chunks XOR (row >> 1) & 7): the
@@ -479,44 +694,22 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
     _Float16* cs2 = w2s + kSlabs * kBN2 * kBK;
     _Float16* ys = cs2;
     _Float16* w3s = cs2 + BM * kBK;                  // [kN3][kBK]
-    const int N2 = pw2.n;
-    constexpr int kNI3 = kN3 > 0 ? kN3 / (16 * kWN) : 1;
-    constexpr int kW3Vecs = kN3 > 0 ? kN3 * 8 / kT : 1;
-    static_assert(kN3 == 0 || (kN3 % (16 * kWN) == 0 && kN3 * 8 % kT == 0), "third GEMM: channel count does not fit the wave layout");
-    unsigned w3_off[kW3Vecs];
     float4v acc3[kNI3][kMI];
     if constexpr (kN3 > 0) {
-#pragma unroll
-      for (int i = 0; i < kW3Vecs; ++i) {
-        const int v = (i * kW + wave) * 64 + lane;
-        const int row = v >> 3;
-        const int chunk = (v & 7) ^ ((row >> 1) & 7);
-        w3_off[i] = static_cast<unsigned>((row * N2 + chunk * 8) * 2);
-      }
 #pragma unroll
       for (int ni = 0; ni < kNI3; ++ni)
 #pragma unroll
         for (int mi = 0; mi < kMI; ++mi) acc3[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
     }
-    const __amdgpu_buffer_rsrc_t w2_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw2.w), 0, N2 * (kSlabs * kBK) * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<_Float16*>(kN3 > 0 ? pw3.w : pw2.w), 0, (kN3 > 0 ? kN3 : kBN2) * N2 * 2, 0x00020000);
-    unsigned w2_off[kW2Vecs];
+    // weight vector v of a chunk sits at 16 * v bytes of its buffer; the thread that loaded it stores it
+    auto store_w2 = [&]() {
 #pragma unroll
-    for (int i = 0; i < kW2Vecs; ++i) {
-      const int v = (i * kW + wave) * 64 + lane;
-      const int slab = v >> 9;  // 512 vectors (64 rows x 8 chunks) per slab
-      const int row = (v & 511) >> 3;
-      const int chunk = (v & 7) ^ ((row >> 1) & 7);
-      w2_off[i] = static_cast<unsigned>((row * (kSlabs * kBK) + slab * kBK + chunk * 8) * 2);
-    }
-    auto issue_w2 = [&](int chunk_index) {
-#pragma unroll
-      for (int i = 0; i < kW2Vecs; ++i)
-        DmaToLds(w2_rsrc, w2_off[i], chunk_index * kBN2 * (kSlabs * kBK) * 2, w2s + (i * kW + wave) * 512);
+      for (int i = 0; i < kW2Vecs; ++i) *reinterpret_cast<uint4v*>(w2s + (i * kW + wave) * 512 + lane * 8) = w2r[i];
     };
-    issue_w2(0);
+    auto store_w3 = [&]() {
+#pragma unroll
+      for (int i = 0; i < kW3Vecs; ++i) *reinterpret_cast<uint4v*>(w3s + (i * kW + wave) * 512 + lane * 8) = w3r[i];
+    };
     if constexpr (kXS > 0) {
       // the extra operand slab: rows m0.. of the block input, 64 channels, straight into the slab after the first result's
       const __amdgpu_buffer_rsrc_t xd_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -535,12 +728,9 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
 #pragma unroll
     for (int ni = 0; ni < kNI; ++ni) {
       const int n_local = wn * (BN / kWN) + ni * 16 + (lane >> 4) * 4;
-      float b[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias != nullptr) {
-        const half4 bv = *reinterpret_cast<const half4*>(bias + n_local);
+      float b[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(bv[r]);
-      }
+      for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(b1r[ni][r]);
 #pragma unroll
       for (int mi = 0; mi < kMI; ++mi) {
         const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
@@ -554,40 +744,21 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         *reinterpret_cast<half4*>(ts + (n_local >> 6) * (BM * kBK) + m_local * kBK + chunk * 8 + (n_local & 7)) = packed;
       }
     }
+    store_w2();  // chunk 0's weights (requested before the K loop)
+    if constexpr (kXS > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the extra operand slab has landed
     const int w2f_off = (wn * (kBN2 / kWN) + frag_row) * kBK + frag_chunk * 8;
     const int chunks = N2 / kBN2;
+    if (chunks > 1) load_w2(1);
     // Output stores go through a buffer descriptor: a row past M gets an out-of-range offset and its
-    // store is dropped, so every wave issues exactly kOutVecs2 store instructions per chunk, without
-    // branches, and the counted waits below can leave them in flight (vector memory operations
-    // complete in issue order) instead of stalling a chunk on the acknowledgement of the previous
-    // chunk's writes.
-    constexpr int kRowVecs2 = kBN2 / 8;
-    constexpr int kOutVecs2 = BM * kRowVecs2 / kT;
-    using uint4v = __attribute__((ext_vector_type(4))) unsigned;
+    // store is dropped, so every wave issues the same store instructions per chunk, without branches.
     const __amdgpu_buffer_rsrc_t y_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(Y, 0, static_cast<int>(static_cast<unsigned>(M) * N2 * 2u), 0x00020000);
     for (int c = 0; c < chunks; ++c) {
-      // in flight, oldest first: chunk c's weights, then the previous chunk's kOutVecs2 output stores
-      if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOutVecs2) : "memory");
-      __syncthreads();  // chunk c's weights (and, the first time, the operand slabs) are in LDS
-      const _Float16* wbuf = w2s;
+      LdsBarrier();  // chunk c's weights (and, the first time, the operand slabs) are in LDS; the third GEMM is done with its buffers
       if constexpr (kN3 > 0) {
         // K columns c*64.. of the next convolution's weights; consumed after this chunk's epilogue
-#pragma unroll
-        for (int i = 0; i < kW3Vecs; ++i) DmaToLds(w3_rsrc, w3_off[i], c * kBN2 * 2, w3s + (i * kW + wave) * 512);
-      }
-      // this chunk's residual rows travel while its MFMAs run (rows past M: the last row, unused)
-      half8 res_ahead[kOutVecs2];
-      if (residual != nullptr) {
-#pragma unroll
-        for (int i = 0; i < kOutVecs2; ++i) {
-          const int v = tid + i * kT;
-          const int row = v / kRowVecs2;
-          const int cv = v - row * kRowVecs2;
-          const int m = m0 + row < M ? m0 + row : M - 1;
-          res_ahead[i] = *reinterpret_cast<const half8*>(residual + static_cast<long long>(m) * N2 + c * kBN2 + cv * 8);
-        }
+        store_w3();
+        if (c + 1 < chunks) load_w3(c + 1);
       }
       float4v acc2[kNI2][kMI];
 #pragma unroll
@@ -599,7 +770,7 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const _Float16* xs = ts + sl * (BM * kBK) + (xf_off ^ (kk * 32));
-          const _Float16* ws = wbuf + sl * (kBN2 * kBK) + (w2f_off ^ (kk * 32));
+          const _Float16* ws = w2s + sl * (kBN2 * kBK) + (w2f_off ^ (kk * 32));
           half8 xf[kMI], wf[kNI2];
 #pragma unroll
           for (int mi = 0; mi < kMI; ++mi) xf[mi] = *reinterpret_cast<const half8*>(xs + mi * 16 * kBK);
@@ -618,9 +789,8 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         const int n_local = wn * (kBN2 / kWN) + ni * 16 + (lane >> 4) * 4;
         float b[4] = {0.f, 0.f, 0.f, 0.f};
         if (pw2.bias != nullptr) {
-          const half4 bv = *reinterpret_cast<const half4*>(pw2.bias + c * kBN2 + n_local);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(bv[r]);
+          for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(b2r[ni][r]);
         }
 #pragma unroll
         for (int mi = 0; mi < kMI; ++mi) {
@@ -631,8 +801,11 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
           *reinterpret_cast<half4*>(cs2 + m_local * kBK + ((((n_local >> 3) ^ ((m_local >> 1) & 7)) << 3) + (n_local & 7))) = packed;
         }
       }
-      __syncthreads();  // the output chunk is in cs2, and every wave is done reading the weight buffer
-      if (c + 1 < chunks) issue_w2(c + 1);  // lands while the rest of this chunk runs
+      LdsBarrier();  // the output chunk is in cs2, and every wave is done reading the weight buffer
+      if (c + 1 < chunks) {
+        store_w2();  // requested one chunk ago
+        if (c + 2 < chunks) load_w2(c + 2);
+      }
       half8 vals[kOutVecs2];
       unsigned y_off[kOutVecs2];
 #pragma unroll
@@ -643,7 +816,7 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         const int m = m0 + row;
         _Float16* slot = cs2 + row * kBK + ((cv ^ ((row >> 1) & 7)) * 8);
         half8 val = *reinterpret_cast<const half8*>(slot);
-        if (residual != nullptr) val = val + res_ahead[i];  // packed fp16 adds: the same rounding as adding in fp32
+        if (residual != nullptr) val = val + res_r[i];  // packed fp16 adds: the same rounding as adding in fp32
         if (relu) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) val[j] = val[j] > static_cast<_Float16>(0) ? val[j] : static_cast<_Float16>(0);
@@ -652,12 +825,12 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
         y_off[i] = m < M ? (static_cast<unsigned>(m) * N2 + c * kBN2 + cv * 8) * 2u : kOutOfRange;
         if constexpr (kN3 > 0) *reinterpret_cast<half8*>(slot) = val;  // finished value back in its own slot (rows past M: unused)
       }
+      if (c + 1 < chunks) {  // what the next chunk's epilogue adds: on its way while that chunk's MFMAs run
+        if (residual != nullptr) load_res(c + 1);
+        if (pw2.bias != nullptr) load_bias2(c + 1);
+      }
       if constexpr (kN3 > 0) {
-        // in flight, oldest first: this chunk's third-GEMM weights, the residual rows (consumed above),
-        // the next chunk's second-GEMM weights: let only the last stay in flight
-        if (c + 1 < chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2Vecs) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // the weights have landed for every wave, and the slab is complete
+        LdsBarrier();  // the slab is complete (the third GEMM's weights were stored two barriers ago)
         const int w3f_off = (wn * (kN3 / kWN) + frag_row) * kBK + frag_chunk * 8;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -675,7 +848,7 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
               acc3[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc3[ni][mi], 0, 0, 0);
         }
       }
-      // last in the chunk, so nothing in it waits for them
+      // last in the chunk, and nothing ever waits for them
 #pragma unroll
       for (int i = 0; i < kOutVecs2; ++i)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, vals[i]), y_rsrc, static_cast<int>(y_off[i]), 0, 0);
@@ -685,16 +858,13 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
       // third result: +bias, ReLU -> transposed through LDS (everything above is idle now) -> coalesced stores
       constexpr int kCPitch3 = kN3 + 8;
       _Float16* cs3 = lds;
-      __syncthreads();
+      LdsBarrier();
 #pragma unroll
       for (int ni = 0; ni < kNI3; ++ni) {
         const int n_local = wn * (kN3 / kWN) + ni * 16 + (lane >> 4) * 4;
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (pw3.bias != nullptr) {
-          const half4 bv = *reinterpret_cast<const half4*>(pw3.bias + n_local);
+        float b[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(bv[r]);
-        }
+        for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(b3r[ni][r]);
 #pragma unroll
         for (int mi = 0; mi < kMI; ++mi) {
           const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
@@ -707,7 +877,7 @@ __global__ __launch_bounds__(128 * kWN) void ConvGemmKernel(const _Float16* __re
           *reinterpret_cast<half4*>(cs3 + m_local * kCPitch3 + n_local) = packed;
         }
       }
-      __syncthreads();
+      LdsBarrier();
       constexpr int kRowVecs3 = kN3 / 8;
       constexpr int kOutVecs3 = BM * kRowVecs3 / kT;
 #pragma unroll
@@ -1056,7 +1226,7 @@ struct SplitK {
   int arrival_slots;
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0>
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0, bool kHalo = false>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, const SplitK& sk,
                   hipStream_t st, const Pointwise2& pw2 = Pointwise2{nullptr, nullptr, 0, nullptr},
@@ -1091,6 +1261,12 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (!kGlds) stages = 2;
   if (stages > ktiles) stages = ktiles;
   size_t lds_bytes = static_cast<size_t>(stages) * (BM + BN) * kBK * sizeof(_Float16);
+  if (kHalo) {
+    if (map.ksize != 3 || map.stride != 1 || map.pad != 1 || splits != 1) return -2;
+    const size_t halo_rows = static_cast<size_t>((BM + 2 * map.in_w + 2) / (8 * 2 * kWN) + 1) * (8 * 2 * kWN);
+    lds_bytes = (static_cast<size_t>(map.cin / kBK) * halo_rows + static_cast<size_t>(stages) * BN) * kBK * sizeof(_Float16);
+    if (lds_bytes > 160 * 1024) return -2;
+  }
   size_t c_bytes = static_cast<size_t>(BM) * (BN + 8) * sizeof(_Float16);
   if (kFuse) {
     if (tiles_n != 1 || splits != 1 || pw2.w == nullptr || pw2.n <= 0 || pw2.n % 64 != 0) return -2;
@@ -1108,11 +1284,11 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
   if (lds_bytes > 64 * 1024) {
     // above the default dynamic-LDS limit: raise it once per kernel instantiation
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS, kHalo>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
   }
-  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st,
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS, kHalo>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st,
                      x, w, bias, residual, y, M, N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages, splits, sk.partials,
                      sk.arrivals, pw2, pw3);
   const hipError_t e = hipGetLastError();
@@ -1267,7 +1443,12 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   const long long blocks = (M + bm - 1) / bm;
   const long long per_cu_wanted = (blocks + 255) / 256;
   const long long per_cu_with_3 = (160 * 1024) / (3 * (bm + mid) * kBK * 2);
-  const int stages = per_cu_wanted <= per_cu_with_3 ? 3 : 2;
+  int stages = per_cu_wanted <= per_cu_with_3 ? 3 : 2;
+  static const int forced_stages = [] {
+    const char* v = std::getenv("TCA_FUSED_STAGES");  // experiments: 2, 3 or 4 stages of the first GEMM's DMA pipeline
+    return v ? std::atoi(v) : 0;
+  }();
+  if (forced_stages >= 2 && forced_stages <= 4) stages = forced_stages;
   auto st = static_cast<hipStream_t>(stream);
   auto xp = static_cast<const _Float16*>(x);
   auto wp = static_cast<const _Float16*>(w1);
@@ -1284,10 +1465,37 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
   } else {
     n3 = 0;
   }
-#define TCA_FUSED(BM_, BN_, N3_) \
-  LaunchConvGemm<BM_, BN_, 4, true, true, true, N3_>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3)
-#define TCA_FUSED_XS(BM_, N3_) \
-  LaunchConvGemm<BM_, 64, 4, true, true, true, N3_, 1>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3)
+  // Halo form of the first GEMM (3x3, stride 1, pad 1): the tile's input rows go to LDS once and the K loop
+  // streams weights only, three stages deep where two blocks per CU still fit (A/B switch: TCA_CONV_HALO=0).
+  static const bool halo_enabled = [] {
+    const char* v = std::getenv("TCA_CONV_HALO");
+    return !(v && v[0] == '0');
+  }();
+  bool halo = halo_enabled && ksize == 3 && stride == 1 && pad == 1;
+  if (halo) {
+    const long long halo_rows = ((bm + 2 * in_w + 2) / 64 + 1) * 64;
+    const long long halo_bytes = (cin / kBK) * halo_rows * kBK * 2;
+    const long long second = (static_cast<long long>(bm) * (mid + (xd ? 64 : 0)) + (mid + (xd ? 64 : 0)) * 64 + bm * 64 + n3 * 64) * 2;
+    const long long budget = second > 80 * 1024 ? second : 80 * 1024;  // never fewer blocks per CU than the fused phase allows
+    if (halo_bytes + 3ll * mid * kBK * 2 <= budget) stages = 3;
+    else if (halo_bytes + 2ll * mid * kBK * 2 <= budget) stages = 2;
+    else halo = false;
+    if (forced_stages >= 2 && forced_stages <= 4 && halo) stages = forced_stages;
+  }
+#define TCA_FUSED(BM_, BN_, N3_)                                                                                             \
+  (halo ? LaunchConvGemm<BM_, BN_, 4, true, true, true, N3_, 0, true>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, \
+                                                                      pw2, pw3)                                              \
+        : LaunchConvGemm<BM_, BN_, 4, true, true, true, N3_>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3))
+#define TCA_FUSED_XS(BM_, N3_)                                                                                               \
+  (halo ? LaunchConvGemm<BM_, 64, 4, true, true, true, N3_, 1, true>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, \
+                                                                     pw2, pw3)                                               \
+        : LaunchConvGemm<BM_, 64, 4, true, true, true, N3_, 1>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3))
+  static const bool four_waves = [] {
+    const char* v = std::getenv("TCA_FUSED_WAVES");  // experiment: 4-wave blocks (64 x 32 per wave) for the 128 x 64 form
+    return v && v[0] == '4';
+  }();
+  if (four_waves && xd == nullptr && bm == 128 && mid == 64 && n3 == 64 && halo)
+    return LaunchConvGemm<128, 64, 2, true, true, true, 64, 0, true>(xp, wp, bp, rp, yp, M, mid, K, relu, map, xb, stages, sk, st, pw2, pw3);
   if (xd != nullptr) {
     if (bm == 64) return n3 == 64 ? TCA_FUSED_XS(64, 64) : TCA_FUSED_XS(64, 0);
     return n3 == 64 ? TCA_FUSED_XS(128, 64) : TCA_FUSED_XS(128, 0);
