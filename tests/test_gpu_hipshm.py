@@ -275,3 +275,31 @@ def test_concurrent_clients_get_their_own_answers(hipshm, gpu_server):
         stats = c.get_inference_statistics("resnet50", as_json=True)["model_stats"][0]
         # requests were merged: fewer executions than requests
         assert int(stats["execution_count"]) < int(stats["inference_stats"]["success"]["count"])
+
+
+@pytest.mark.parametrize("round_nearest", [False, True])
+def test_bf16_region_from_gpu_and_host_tensors(hipshm, round_nearest):
+    """fp32 -> BF16 into a region: a GPU tensor is converted by the kernel straight into the region, a
+    host array on the host; both give the bytes of the reference codec (truncation) or of
+    round-to-nearest-even, and read back as the fp32 values those bytes stand for."""
+    import torch
+    from tritonclient.utils import serialize_bf16_tensor
+
+    n = 1 << 20  # 4 MiB of fp32
+    host = (np.random.default_rng(3).standard_normal(n) * 100).astype(np.float32)
+    host[:4] = [0.0, -0.0, np.inf, 1.0000001]
+    gpu = torch.from_numpy(host).cuda(0)
+    h = hipshm.create_shared_memory_region("bf16_data", 4 * n, 0)
+    try:
+        written = hipshm.set_shared_memory_region_bf16(h, [gpu, host], round_nearest=round_nearest)
+        assert written == 4 * n
+        raw = hipshm.get_contents_as_numpy(h, np.uint16, [2, n])
+        np.testing.assert_array_equal(raw[0], raw[1])  # kernel == host conversion, bit for bit
+        if not round_nearest:
+            assert raw[1].tobytes() == serialize_bf16_tensor(host).item()
+        back = hipshm.get_contents_as_numpy_bf16(h, [2, n])
+        np.testing.assert_array_equal(back[0], (raw[0].astype(np.uint32) << 16).view(np.float32))
+        rel = np.abs(back[0][4:] - host[4:]) / np.maximum(np.abs(host[4:]), 1e-30)
+        assert rel.max() <= (2.0 ** -8 if round_nearest else 2.0 ** -7)
+    finally:
+        hipshm.destroy_shared_memory_region(h)

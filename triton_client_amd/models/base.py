@@ -55,6 +55,8 @@ class ExecContext:
     version: str = "1"
     requested_outputs: Optional[List[str]] = None
     stable_inputs: set = field(default_factory=set)  # inputs aliasing registered device shm
+    # BYTES outputs bound for device shared memory: name -> ops.bytes_pipe.DeviceBytes of the destination range
+    output_destinations: Dict[str, object] = field(default_factory=dict)
 
 
 class ModelError(Exception):

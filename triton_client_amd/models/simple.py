@@ -15,6 +15,8 @@ Contracts (reference examples, ``src/python/examples``):
 
 from __future__ import annotations
 
+import math
+import os
 import time
 
 import numpy as np
@@ -77,15 +79,161 @@ class VersionedAddSub(Model):
         return {"OUTPUT0": a + b, "OUTPUT1": a - b}
 
 
+class _DeviceBytesPath:
+    """BYTES models that can serve a request without its tensors leaving the GPU.
+
+    When every input of a request is a :class:`~triton_client_amd.ops.bytes_pipe.DeviceBytes`
+    (a range of a device shared-memory region) and every output has a device destination, the
+    request joins a queue that one thread drains in batches: prefix walk, the model's operation
+    and the packing into the callers' regions run as three kernel launches per batch
+    (``csrc/hip/bytes_models.hip``).  Any other request takes the host path of ``execute``."""
+
+    device_bytes = True
+    device_op = None          # bytes_pipe.OP_*
+    device_outputs = ()       # output names in kernel order
+
+    def _device_job(self, inputs, ctx):
+        """(count, input tensors, destinations) when the request qualifies for the device path."""
+        dests = ctx.output_destinations
+        if not dests:
+            return None
+        ins = [inputs.get(t.name) for t in self.inputs]
+        first = ins[0] if ins else None
+        if first is None:
+            return None
+        DeviceBytes, limit = _device_bytes_types()
+        count = math.prod(first.shape) if type(first) is DeviceBytes else 0
+        if count <= 0 or count > 4096:
+            return None
+        for t in ins:
+            if type(t) is not DeviceBytes or t.nbytes > limit or t.device != first.device or math.prod(t.shape) != count:
+                return None
+        wanted = ctx.requested_outputs
+        if wanted is not None and (len(wanted) != len(self.device_outputs) or set(wanted) != set(self.device_outputs)):
+            return None
+        try:
+            return count, ins, [dests[n] for n in self.device_outputs]
+        except KeyError:
+            return None
+
+    def execute_async(self, inputs, ctx, callback):
+        """Queue the request on the device path; ``callback(result, error)`` runs on the batch thread.
+        Returns False (nothing queued) when the request does not qualify."""
+        job = self._device_job(inputs, ctx)
+        if job is None:
+            return False
+        self._ensure_worker(job[1][0].device)
+        self._jobs.put((job, callback))
+        return True
+
+    def _ensure_worker(self, device):
+        import queue
+        import threading
+
+        if getattr(self, "_jobs", None) is None:
+            with _WORKER_LOCK:
+                if getattr(self, "_jobs", None) is None:
+                    self._pipes = {}
+                    jobs = queue.Queue()
+                    target = lambda: self._drain(jobs)  # noqa: E731
+                    if os.environ.get("TCA_PROFILE_DIR"):  # developer aid: per-request Python cost of the batch thread
+                        from ..server.batcher import _profiled
+
+                        target = _profiled(target, f"bytes-{self.name}")
+                    threading.Thread(target=target, name=f"tca-bytes-{self.name}", daemon=True).start()
+                    self._jobs = jobs
+
+    def _drain(self, jobs):
+        from ..ops import _device
+        from ..ops.bytes_pipe import STATUS_TEXT, BytesPipe, DeviceBytesResult
+
+        max_batch = 64
+        streams = {}
+        while True:
+            first = jobs.get()
+            if first is None:
+                return
+            batch = [first]
+            while len(batch) < max_batch:
+                try:
+                    nxt = jobs.get_nowait()
+                except Exception:
+                    break
+                if nxt is None:
+                    jobs.put(None)
+                    break
+                batch.append(nxt)
+            groups = {}
+            for item in batch:
+                (count, ins, _), _ = item
+                groups.setdefault((ins[0].device, count), []).append(item)
+            for (device, count), items in groups.items():
+                try:
+                    pipe = self._pipes.get(device)
+                    if pipe is None:
+                        pipe = self._pipes[device] = BytesPipe(device, max_batch, 4096)
+                        streams[device] = _device.Stream(device)
+                    in_ptrs, in_bytes, out_ptrs, out_caps = [], [], [], []
+                    for (_, ins, dests), _ in items:
+                        for t in ins:
+                            in_ptrs.append(t.address)
+                            in_bytes.append(t.nbytes)
+                        for d in dests:
+                            out_ptrs.append(d.address)
+                            out_caps.append(d.nbytes)
+                    codes, produced = pipe.run(self.device_op, count, in_ptrs, in_bytes, out_ptrs, out_caps,
+                                               streams[device].handle)
+                    for ((_, ins, _), callback), code, sizes in zip(items, codes, produced):
+                        if code:
+                            callback(None, ModelError(f"{self.name}: {STATUS_TEXT.get(code, 'device BYTES path failed')}"))
+                        else:
+                            callback({name: DeviceBytesResult(ins[0].shape, size)
+                                      for name, size in zip(self.device_outputs, sizes)}, None)
+                except Exception as e:  # noqa: BLE001 - every caller of the group gets the failure
+                    for _, callback in items:
+                        callback(None, ModelError(f"{self.name}: device BYTES path failed: {e}"))
+
+    def _host_inputs(self, inputs):
+        """Inputs for the host path: device-resident BYTES tensors are fetched and parsed."""
+        from ..ops.bytes_pipe import DeviceBytes
+
+        return {k: (v.to_host() if isinstance(v, DeviceBytes) else v) for k, v in inputs.items()}
+
+    def unload(self):
+        jobs = getattr(self, "_jobs", None)
+        if jobs is not None:
+            jobs.put(None)
+            self._jobs = None
+
+
+import threading as _threading  # noqa: E402
+
+_WORKER_LOCK = _threading.Lock()
+_DEVICE_BYTES_TYPES = None
+
+
+def _device_bytes_types():
+    """(DeviceBytes class, largest stream the kernels take), resolved once."""
+    global _DEVICE_BYTES_TYPES
+    if _DEVICE_BYTES_TYPES is None:
+        from ..ops.bytes_pipe import DeviceBytes, max_stream_bytes
+
+        _DEVICE_BYTES_TYPES = (DeviceBytes, max_stream_bytes())
+    return _DEVICE_BYTES_TYPES
+
+
 @register
-class SimpleString(Model):
+class SimpleString(_DeviceBytesPath, Model):
     name = "simple_string"
     inline = True  # microseconds of host work: transports may run it on their own thread
     max_batch_size = 8
     inputs = [TensorSpec("INPUT0", "BYTES", [16]), TensorSpec("INPUT1", "BYTES", [16])]
     outputs = [TensorSpec("OUTPUT0", "BYTES", [16]), TensorSpec("OUTPUT1", "BYTES", [16])]
+    device_op = 0
+    device_outputs = ("OUTPUT0", "OUTPUT1")
 
     def execute(self, inputs, ctx):
+        inputs = self._host_inputs(inputs)
         try:
             a = np.array([int(x) for x in inputs["INPUT0"].reshape(-1)], dtype=np.int64)
             b = np.array([int(x) for x in inputs["INPUT1"].reshape(-1)], dtype=np.int64)
@@ -99,15 +247,17 @@ class SimpleString(Model):
 
 
 @register
-class SimpleIdentity(Model):
+class SimpleIdentity(_DeviceBytesPath, Model):
     name = "simple_identity"
     inline = True  # microseconds of host work: transports may run it on their own thread
     max_batch_size = 8
     inputs = [TensorSpec("INPUT0", "BYTES", [-1])]
     outputs = [TensorSpec("OUTPUT0", "BYTES", [-1])]
+    device_op = 1
+    device_outputs = ("OUTPUT0",)
 
     def execute(self, inputs, ctx):
-        return {"OUTPUT0": inputs["INPUT0"]}
+        return {"OUTPUT0": self._host_inputs(inputs)["INPUT0"]}
 
 
 @register

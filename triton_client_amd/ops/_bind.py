@@ -67,6 +67,19 @@ def install(lib):
     lib.tca_flag_set.argtypes = [c_void_p, c_void_p, c_uint32, c_int]
     lib.tca_flag_wait.restype = c_int
     lib.tca_flag_wait.argtypes = [c_void_p, c_void_p, c_uint32, c_int, c_uint32, c_void_p]
+    lib.tca_bytes_pipe_error.restype = c_char_p
+    lib.tca_bytes_pipe_error.argtypes = []
+    lib.tca_bytes_pipe_max_stream_bytes.restype = c_int
+    lib.tca_bytes_pipe_max_stream_bytes.argtypes = []
+    lib.tca_bytes_pipe_create.restype = c_int
+    lib.tca_bytes_pipe_create.argtypes = [c_int, c_int, c_int, POINTER(c_void_p)]
+    lib.tca_bytes_pipe_destroy.restype = None
+    lib.tca_bytes_pipe_destroy.argtypes = [c_void_p]
+    lib.tca_bytes_pipe_submit.restype = c_int
+    lib.tca_bytes_pipe_submit.argtypes = [c_void_p, c_int, c_int, c_int, POINTER(c_uint64), POINTER(c_uint64),
+                                          POINTER(c_uint64), POINTER(c_uint64), c_void_p]
+    lib.tca_bytes_pipe_wait.restype = c_int
+    lib.tca_bytes_pipe_wait.argtypes = [c_void_p, c_int, POINTER(c_uint32), POINTER(c_uint64)]
     lib.tca_hip_device_synchronize.restype = c_int
     lib.tca_hip_device_synchronize.argtypes = [c_int]
 

@@ -473,6 +473,17 @@ def _decode_json(datatype, shape, data, name):
 
 ASYNC = object()  # returned by InferenceCore.infer when the answer comes through on_done
 
+_DEVICE_BYTES = None
+
+
+def _device_bytes_class():
+    global _DEVICE_BYTES
+    if _DEVICE_BYTES is None:
+        from ..ops.bytes_pipe import DeviceBytes
+
+        _DEVICE_BYTES = DeviceBytes
+    return _DEVICE_BYTES
+
 
 class _UnstableDeviceTensor:
     """Marks a device tensor that was copied out of a shared-memory region (so its address is
@@ -833,6 +844,10 @@ class InferenceCore:
                 torch.cuda.current_stream(copy.device).synchronize()  # consumers run on other streams
                 return _UnstableDeviceTensor(copy)
             return view
+        if (t.datatype == "BYTES" and getattr(model, "device_bytes", False) and not mapping.host_backed
+                and ref.byte_size > 0):
+            # the model can walk the stream on the GPU: hand over the range, not a host copy
+            return _device_bytes_class()(mapping.address + ref.offset, ref.byte_size, shape, mapping, ref.offset, device_id)
         deferred.append((t, shape, mapping, ref))  # read together with the request's other ranges
         return None
 
@@ -998,6 +1013,14 @@ class InferenceCore:
                     return lm.batcher.submit(req, inputs, batch, stable, requested, ctx, stats, t_arrive, version)
                 return self._run_gpu_single(lm, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version)
             t1 = time.perf_counter_ns()
+            if getattr(model, "device_bytes", False):
+                queued = self._run_device_bytes(lm, req, inputs, ctx, requested, out_specs, version, batch, stats,
+                                                t_arrive, t0, t1, on_done)
+                if queued is ASYNC:
+                    handed_over = True
+                    return ASYNC
+                if queued is not None:
+                    return queued
             with lm.exec_lock:
                 t_exec = time.perf_counter_ns()
                 result = model.execute(inputs, ctx)
@@ -1018,6 +1041,59 @@ class InferenceCore:
         finally:
             if not handed_over:
                 self.release_request(req)
+
+    def _run_device_bytes(self, lm, req, inputs, ctx, requested, out_specs, version, batch, stats, t_arrive, t0, t1,
+                          on_done):
+        """BYTES tensors that sit in device shared memory, for a model with a device path: the
+        request is queued for the model's batch thread.  With ``on_done`` the answer is delivered
+        from there (returns :data:`ASYNC`); without, this thread waits for it.  Returns None when
+        the request does not qualify (the caller then runs the host path)."""
+        DeviceBytes = _device_bytes_class()
+        if not any(type(v) is DeviceBytes for v in inputs.values()):
+            return None
+        for ro in requested:
+            if ro.shm is None or ro.class_count or out_specs[ro.name].datatype != "BYTES":
+                continue
+            entry = self.devshm.get(ro.shm.region)
+            if entry is None or entry[2].host_backed:
+                continue
+            if ro.shm.offset + ro.shm.byte_size > entry[1]:
+                raise ServerError(f"Invalid offset + byte size for shared memory region: '{ro.shm.region}'", 400)
+            ctx.output_destinations[ro.name] = DeviceBytes(entry[2].address + ro.shm.offset, ro.shm.byte_size, (),
+                                                           entry[2], ro.shm.offset, entry[0])
+        waiter = threading.Event() if on_done is None else None
+        box = []
+
+        def finish(result, error):
+            response = None
+            try:
+                if error is None:
+                    response = self._build_response(lm, req, result, requested, out_specs, version, batch)
+                    now = time.perf_counter_ns()
+                    stats.record(batch, t0 - t_arrive, t1 - t0, now - t1, 0)
+                else:
+                    stats.record_fail(time.perf_counter_ns() - t_arrive)
+                    error = error if isinstance(error, ServerError) else ServerError(str(error), 400)
+            except ServerError as e:
+                error = e
+            except Exception as e:  # noqa: BLE001
+                error = ServerError(f"internal error: {type(e).__name__}: {e}", 500)
+            if waiter is None:
+                self.release_request(req)
+                on_done(response if error is None else None, error)
+            else:
+                box.append((response, error))
+                waiter.set()
+
+        if not lm.model.execute_async(inputs, ctx, finish):
+            return None
+        if waiter is None:
+            return ASYNC
+        waiter.wait()
+        response, error = box[0]
+        if error is not None:
+            raise error
+        return response
 
     # -- GPU helpers (torch imported lazily: CPU-only servers never need it) --
     def _to_device(self, lm, inputs, stable):
@@ -1092,6 +1168,9 @@ class InferenceCore:
             preplaced = dev_inputs is not None and ("__out__" + ro.name) in dev_inputs and \
                 value is dev_inputs["__out__" + ro.name]
             if preplaced:
+                response.outputs.append(OutputTensor(ro.name, spec.datatype, list(value.shape), None, ro.shm))
+                continue
+            if type(value).__name__ == "DeviceBytesResult":  # written into its device destination by the model
                 response.outputs.append(OutputTensor(ro.name, spec.datatype, list(value.shape), None, ro.shm))
                 continue
             datatype = spec.datatype

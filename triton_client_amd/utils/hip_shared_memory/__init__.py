@@ -217,33 +217,70 @@ def get_contents_as_numpy(shm_handle, datatype, shape, offset=0):
         if need == 0:
             return np.empty(shape, dtype=dt)
         return _read(shm_handle, offset, need).view(dt).reshape(shape)
-    # BYTES: element sizes are unknown up front -> fetch the tail of the region
-    # once and parse `count` elements out of it
-    from .. import shared_memory as _sys  # noqa: F401  (keeps error codes in one place)
-    from .. import _fast
-
-    blob = _read(shm_handle, offset, shm_handle.byte_size - offset)
+    # BYTES: element sizes are unknown up front
     try:
-        if _fast is not None:
-            items = _fast.unpack_bytes(blob.data, count)
-        else:
-            import struct
-
-            items, pos = [], 0
-            raw = blob.tobytes()
-            for _ in range(count):
-                (n,) = struct.unpack_from("<I", raw, pos)
-                pos += 4
-                if pos + n > len(raw):
-                    raise ValueError
-                items.append(raw[pos: pos + n])
-                pos += n
-    except Exception:
+        items = _read_bytes_elements(shm_handle, count, int(offset))
+    except ValueError:
         raise HipSharedMemoryException("malformed BYTES tensor in device shared memory region") from None
     out = np.empty(count, dtype=np.object_)
     for i, item in enumerate(items):
         out[i] = item
     return out.reshape(shape)
+
+
+_INDEX_MAGIC = 0x58444942  # "BIDX": index trailer written behind BYTES results by the server's device path
+_WALK_CHUNK = 4096
+
+
+def _read_bytes_elements(shm_handle, count, offset):
+    """``count`` BYTES elements that start at ``offset``, copying only what they occupy.
+
+    Fast path: a server that produced the tensor on the GPU leaves an index in the last bytes of
+    the region ({magic, count, payload starts, end of stream}).  If it is there AND agrees with
+    the length prefixes of the stream, the stream is fetched in one copy of exactly its size.
+    Otherwise the prefixes are walked over reads of a few KiB, growing as needed - never the whole
+    tail of the region (the reference copies the entire region first:
+    ``tritonclient/utils/cuda_shared_memory/__init__.py:265-276``)."""
+    if count == 0:
+        return []
+    size = shm_handle.byte_size - offset
+    need = 12 + 4 * count
+    if size >= need + 3:
+        at = ((shm_handle.address + shm_handle.byte_size - need) & ~3) - shm_handle.address
+        if at >= offset + 4 * count:
+            t = _read(shm_handle, at, need).view(np.uint32)
+            if int(t[0]) == _INDEX_MAGIC and int(t[1]) == count:
+                starts = t[2: 2 + count].astype(np.int64)
+                end = int(t[2 + count])
+                if int(starts[0]) == 4 and end <= at - offset and bool(np.all(np.diff(starts) >= 4)) and \
+                        int(starts[-1]) <= end:
+                    blob = _read(shm_handle, offset, end)
+                    nxt = np.append(starts[1:] - 4, end)
+                    lens = nxt - starts
+                    idx = starts - 4
+                    prefix = (blob[idx].astype(np.int64) | (blob[idx + 1].astype(np.int64) << 8)
+                              | (blob[idx + 2].astype(np.int64) << 16) | (blob[idx + 3].astype(np.int64) << 24))
+                    if bool(np.all(prefix == lens)):  # the index describes THIS stream
+                        raw = blob.tobytes()
+                        return [raw[int(s0): int(s0 + n)] for s0, n in zip(starts, lens)]
+    # walk the prefixes over incremental reads
+    have = np.empty(0, dtype=np.uint8)
+    items, pos = [], 0
+    chunk = _WALK_CHUNK
+    while len(items) < count:
+        if pos + 4 > len(have) or (pos + 4 <= len(have) and pos + 4 + int.from_bytes(have[pos: pos + 4].tobytes(), "little") > len(have)):
+            want = pos + 4 if pos + 4 > len(have) else pos + 4 + int.from_bytes(have[pos: pos + 4].tobytes(), "little")
+            if want > size:
+                raise ValueError("stream runs past the region")
+            upto = min(size, max(want, len(have) + chunk))
+            more = _read(shm_handle, offset + len(have), upto - len(have))
+            have = np.concatenate([have, more]) if len(have) else more
+            chunk *= 2
+            continue
+        n = int.from_bytes(have[pos: pos + 4].tobytes(), "little")
+        items.append(have[pos + 4: pos + 4 + n].tobytes())
+        pos += 4 + n
+    return items
 
 
 _DEVICE_TYPES = (_dlpack.DLDeviceType.kDLROCM, _dlpack.DLDeviceType.kDLCUDA)
@@ -285,6 +322,72 @@ def set_shared_memory_region_from_dlpack(shm_handle, input_values, offset=0):
                "unable to set values in device shared memory")
         cursor += nbytes
         del capsule
+
+
+def set_shared_memory_region_bf16(shm_handle, input_values, offset=0, round_nearest=False):
+    """fp32 tensors -> BF16 wire form (2 bytes per element, the upper half of the fp32 bits; the
+    reference truncates: ``tritonclient/utils/__init__.py:310-320``) back-to-back in the region.
+
+    fp32 tensors that live on a GPU (anything with ``__dlpack__``, e.g. torch-ROCm) are converted
+    by the GPU kernel straight into the region - no host copy, no intermediate tensor; host arrays
+    are truncated on the host and copied (half the bytes cross the bus).  Not in the reference API,
+    which has no device-side producer.  Returns the number of bytes written."""
+    from .. import serialize_bf16_tensor
+
+    cursor = int(offset)
+    for value in input_values:
+        device = _dlpack.get_dlpack_device(value) if hasattr(value, "__dlpack__") else None
+        if device is not None and device[0] in _DEVICE_TYPES and not shm_handle.host_backed:
+            try:
+                capsule = value.__dlpack__(stream=0)
+            except TypeError:
+                capsule = value.__dlpack__()
+            t = _dlpack.get_managed_tensor(capsule).dl_tensor
+            if not _dlpack.is_contiguous_data(t.ndim, t.shape, t.strides):
+                raise HipSharedMemoryException("DLPack tensor is not contiguous")
+            if (int(t.dtype.type_code), int(t.dtype.bits), int(t.dtype.lanes)) != (2, 32, 1):  # kDLFloat
+                raise HipSharedMemoryException("BF16 regions are filled from fp32 tensors")
+            if t.device.device_id != shm_handle.device_id:
+                raise HipSharedMemoryException("the tensor and the region sit on different GPUs")
+            count = 1
+            for i in range(t.ndim):
+                count *= t.shape[i]
+            if cursor + 2 * count > shm_handle.byte_size:
+                raise HipSharedMemoryException("the region is too small for the tensor")
+            if cursor % 2:
+                raise HipSharedMemoryException("BF16 tensors start at even offsets")
+            lib = _lib()
+            rc = lib.tca_fp32_to_bf16_launch((t.data or 0) + t.byte_offset, shm_handle.address + cursor, count,
+                                             1 if round_nearest else 0, None)
+            _check(rc, "fp32 -> bf16 conversion failed")
+            _check(lib.tca_hip_device_synchronize(shm_handle.device_id), "unable to synchronize the device")
+            cursor += 2 * count
+            del capsule
+            continue
+        arr = np.ascontiguousarray(np.asarray(value if not hasattr(value, "cpu") else value.cpu()), dtype=np.float32)
+        if round_nearest:
+            bits = arr.view(np.uint32).astype(np.uint64)
+            packed = (((bits + 0x7FFF + ((bits >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+            nan = np.isnan(arr)
+            if nan.any():
+                packed[nan] = (arr.view(np.uint32)[nan] >> 16).astype(np.uint16) | 0x40
+        else:
+            blob = serialize_bf16_tensor(arr)
+            packed = np.frombuffer(blob.item() if blob.size else b"", dtype=np.uint16)
+        set_shared_memory_region(shm_handle, [packed], offset=cursor)
+        cursor += packed.nbytes
+    return cursor - int(offset)
+
+
+def get_contents_as_numpy_bf16(shm_handle, shape, offset=0):
+    """A BF16 tensor of ``shape`` in the region as a float32 array: two bytes per element cross the
+    bus and are widened on the host."""
+    count = int(np.prod(shape)) if len(shape) else 1
+    if offset + 2 * count > shm_handle.byte_size:
+        raise HipSharedMemoryException(
+            "The size of the shared memory region is insufficient to provide numpy array with requested size")
+    half = _read(shm_handle, offset, 2 * count).view(np.uint16)
+    return (half.astype(np.uint32) << 16).view(np.float32).reshape(shape)
 
 
 def as_shared_memory_tensor(shm_handle, datatype, shape, offset=0):
