@@ -67,8 +67,55 @@ int HttpToGrpc(int http_status) {
 
 }  // namespace
 
+namespace {
+// what h2::Connection advertises unless told otherwise
+constexpr uint32_t kDefaultStreamWindow = 8u << 20, kDefaultConnectionWindow = 64u << 20, kDefaultMaxFrame = 1u << 20;
+}  // namespace
+
+Error ChannelOptions::SetInt(const std::string& arg, int64_t value) {
+  if (arg == "grpc.max_send_message_length") max_send_message_bytes = value < 0 ? INT64_MAX : value;
+  else if (arg == "grpc.max_receive_message_length") max_receive_message_bytes = value < 0 ? INT64_MAX : value;
+  else if (arg == "grpc.keepalive_time_ms") keepalive.keepalive_time_ms = static_cast<int>(value);
+  else if (arg == "grpc.keepalive_timeout_ms") keepalive.keepalive_timeout_ms = static_cast<int>(value);
+  else if (arg == "grpc.keepalive_permit_without_calls") keepalive.keepalive_permit_without_calls = value != 0;
+  else if (arg == "grpc.http2.max_pings_without_data") keepalive.http2_max_pings_without_data = static_cast<int>(value);
+  else if (arg == "grpc.http2.lookahead_bytes" || arg == "grpc.http2.stream_window_bytes")
+    http2_stream_window_bytes = static_cast<uint32_t>(value);
+  else if (arg == "grpc.http2.connection_window_bytes") http2_connection_window_bytes = static_cast<uint32_t>(value);
+  else if (arg == "grpc.http2.max_frame_size") http2_max_frame_bytes = static_cast<uint32_t>(value);
+  else if (arg == "triton_client_channel_idx") (void)value;  // the reference's trick against grpc's own channel sharing: nothing to do
+  else return Error("unsupported integer channel argument '" + arg + "'");
+  return Error::Success();
+}
+
+Error ChannelOptions::SetString(const std::string& arg, const std::string& value) {
+  if (arg == "grpc.primary_user_agent") primary_user_agent = value;
+  else return Error("unsupported string channel argument '" + arg + "'");
+  return Error::Success();
+}
+
+std::string ChannelOptions::CacheKey() const {
+  return std::to_string(keepalive.keepalive_time_ms) + "," + std::to_string(keepalive.keepalive_timeout_ms) + "," +
+         std::to_string(keepalive.keepalive_permit_without_calls) + "," +
+         std::to_string(keepalive.http2_max_pings_without_data) + "," + std::to_string(max_send_message_bytes) + "," +
+         std::to_string(max_receive_message_bytes) + "," + primary_user_agent + "," +
+         std::to_string(http2_stream_window_bytes) + "," + std::to_string(http2_connection_window_bytes) + "," +
+         std::to_string(http2_max_frame_bytes);
+}
+
 Error GrpcChannel::Create(std::shared_ptr<GrpcChannel>* channel, const std::string& url, bool verbose,
                           const KeepAliveOptions& keepalive, std::shared_ptr<net::TlsContext> tls) {
+  ChannelOptions options;
+  options.keepalive = keepalive;
+  return Create(channel, url, verbose, options, std::move(tls));
+}
+
+Error GrpcChannel::Create(std::shared_ptr<GrpcChannel>* channel, const std::string& url, bool verbose,
+                          const ChannelOptions& options, std::shared_ptr<net::TlsContext> tls) {
+  if (options.http2_max_frame_bytes != 0 && (options.http2_max_frame_bytes < 16384 || options.http2_max_frame_bytes > 16777215))
+    return Error("http2_max_frame_bytes must be within [16384, 16777215]");
+  if ((options.http2_stream_window_bytes | options.http2_connection_window_bytes) > 0x7FFFFFFFu)
+    return Error("HTTP/2 windows are at most 2^31 - 1 bytes");
   std::string u = url;
   const size_t scheme = u.find("://");
   if (scheme != std::string::npos) u = u.substr(scheme + 3);
@@ -83,13 +130,14 @@ Error GrpcChannel::Create(std::shared_ptr<GrpcChannel>* channel, const std::stri
     }
   }
   if (host.empty()) return Error("invalid gRPC url '" + url + "'");
-  channel->reset(new GrpcChannel(url, host, port, verbose, keepalive, std::move(tls)));
+  channel->reset(new GrpcChannel(url, host, port, verbose, options, std::move(tls)));
   return Error::Success();
 }
 
-GrpcChannel::GrpcChannel(std::string url, std::string host, int port, bool verbose, const KeepAliveOptions& keepalive,
+GrpcChannel::GrpcChannel(std::string url, std::string host, int port, bool verbose, const ChannelOptions& options,
                          std::shared_ptr<net::TlsContext> tls)
-    : url_(std::move(url)), host_(std::move(host)), port_(port), verbose_(verbose), keepalive_(keepalive),
+    : url_(std::move(url)), host_(std::move(host)), port_(port), verbose_(verbose), options_(options),
+      keepalive_(options.keepalive),
       tls_context_(std::move(tls)) {
   epfd_ = epoll_create1(EPOLL_CLOEXEC);
   wake_fd_ = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);
@@ -206,6 +254,11 @@ bool GrpcChannel::EnsureConnected(std::string* why) {
     for (uint64_t id : dead) Finish(id, kGrpcUnavailable, "server is going away");
   };
   conn_.reset(new h2::Connection(h2::Connection::Role::CLIENT, std::move(cb)));
+  if (options_.http2_stream_window_bytes || options_.http2_connection_window_bytes || options_.http2_max_frame_bytes)
+    conn_->SetLocalWindow(options_.http2_stream_window_bytes ? options_.http2_stream_window_bytes : kDefaultStreamWindow,
+                          options_.http2_connection_window_bytes ? options_.http2_connection_window_bytes
+                                                                 : kDefaultConnectionWindow,
+                          options_.http2_max_frame_bytes ? options_.http2_max_frame_bytes : kDefaultMaxFrame);
   conn_->Start();
   epoll_event ev{};
   ev.events = EPOLLIN | EPOLLOUT | EPOLLET | EPOLLRDHUP;
@@ -271,7 +324,8 @@ void GrpcChannel::OpenCallStream(uint64_t id, Call* call) {
   h.push_back({":authority", host_ + ":" + std::to_string(port_)});
   h.push_back({"te", "trailers"});
   h.push_back({"content-type", "application/grpc"});
-  h.push_back({"user-agent", "tca-grpc-cpp/1.0"});
+  h.push_back({"user-agent", options_.primary_user_agent.empty() ? std::string("tca-grpc-cpp/1.0")
+                                                                 : options_.primary_user_agent + " tca-grpc-cpp/1.0"});
   h.push_back({"grpc-accept-encoding", "identity,deflate,gzip"});
   if (call->timeout_us) h.push_back({"grpc-timeout", GrpcTimeout(call->timeout_us)});
   for (const auto& kv : call->metadata) {
@@ -364,6 +418,12 @@ void GrpcChannel::OnData(uint32_t stream, const uint8_t* data, size_t len, bool 
     const uint8_t* p = reinterpret_cast<const uint8_t*>(call.rbuf.data()) + off;
     const size_t n = (static_cast<size_t>(p[1]) << 24) | (static_cast<size_t>(p[2]) << 16) |
                      (static_cast<size_t>(p[3]) << 8) | p[4];
+    if (static_cast<int64_t>(n) > options_.max_receive_message_bytes) {
+      conn_->ResetStream(stream, h2::kCancel);
+      Finish(id, kGrpcResourceExhausted, "Received message larger than max (" + std::to_string(n) + " vs. " +
+                                             std::to_string(options_.max_receive_message_bytes) + ")");
+      return;
+    }
     if (call.rbuf.size() - off - 5 < n) break;
     std::string message(call.rbuf, off + 5, n);
     off += 5 + n;

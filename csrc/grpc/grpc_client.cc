@@ -504,8 +504,17 @@ InferenceServerGrpcClient::~InferenceServerGrpcClient() {
 Error InferenceServerGrpcClient::Create(std::unique_ptr<InferenceServerGrpcClient>* client, const std::string& server_url,
                                         bool verbose, bool use_ssl, const SslOptions& ssl_options,
                                         const KeepAliveOptions& keepalive_options, bool use_cached_channel) {
+  ChannelOptions options;
+  options.keepalive = keepalive_options;
+  return Create(client, server_url, options, verbose, use_ssl, ssl_options, use_cached_channel);
+}
+
+Error InferenceServerGrpcClient::Create(std::unique_ptr<InferenceServerGrpcClient>* client, const std::string& server_url,
+                                        const ChannelOptions& channel_options, bool verbose, bool use_ssl,
+                                        const SslOptions& ssl_options, bool use_cached_channel) {
   std::shared_ptr<net::TlsContext> tls;
-  std::string cache_key = server_url;
+  // a channel is only shared between clients that asked for the same settings
+  std::string cache_key = server_url + "|" + channel_options.CacheKey();
   if (use_ssl) {
     net::TlsOptions opt;
     opt.ca_file = ssl_options.root_certificates;
@@ -524,12 +533,12 @@ Error InferenceServerGrpcClient::Create(std::unique_ptr<InferenceServerGrpcClien
     if (channel && entry.shares < MaxShareCount()) {
       ++entry.shares;
     } else {
-      TCA_RETURN_IF_ERROR(GrpcChannel::Create(&channel, server_url, verbose, keepalive_options, tls));
+      TCA_RETURN_IF_ERROR(GrpcChannel::Create(&channel, server_url, verbose, channel_options, tls));
       entry.channel = channel;
       entry.shares = 1;
     }
   } else {
-    TCA_RETURN_IF_ERROR(GrpcChannel::Create(&channel, server_url, verbose, keepalive_options, tls));
+    TCA_RETURN_IF_ERROR(GrpcChannel::Create(&channel, server_url, verbose, channel_options, tls));
   }
   client->reset(new InferenceServerGrpcClient(std::move(channel), verbose));
   return Error::Success();
@@ -562,6 +571,10 @@ Error InferenceServerGrpcClient::Unary(const std::string& method, const std::str
     sync->done = true;
     sync->cv.notify_all();
   };
+  if (static_cast<int64_t>(request.size()) > channel_->Options().max_send_message_bytes)
+    return Error("Sent message larger than max (" + std::to_string(request.size()) + " vs. " +
+                     std::to_string(channel_->Options().max_send_message_bytes) + ")",
+                 kGrpcResourceExhausted);
   const uint64_t call = channel_->StartCall(method, headers, timeout_us, std::move(ev));
   channel_->SendMessage(call, std::string(request), true, compressed);
   std::unique_lock<std::mutex> lk(sync->mu);
@@ -572,14 +585,14 @@ Error InferenceServerGrpcClient::Unary(const std::string& method, const std::str
 }
 
 Error InferenceServerGrpcClient::JsonCall(const std::string& method, const std::string& request_json,
-                                          const Headers& headers, std::string* response_json) {
+                                          const Headers& headers, std::string* response_json, uint64_t timeout_us) {
   int req_msg = -1, resp_msg = -1;
   if (!pb::FindMethod(method, &req_msg, &resp_msg)) return Error("unknown RPC method '" + method + "'");
   json::Value req;
   TCA_RETURN_IF_ERROR(json::Parse(request_json.data(), request_json.size(), &req));
   std::string wire, reply;
   TCA_RETURN_IF_ERROR(pb::FromJson(req_msg, req, &wire));
-  TCA_RETURN_IF_ERROR(Unary(method, wire, headers, 0, &reply));
+  TCA_RETURN_IF_ERROR(Unary(method, wire, headers, timeout_us, &reply));
   json::Value resp;
   TCA_RETURN_IF_ERROR(pb::ToJson(resp_msg, reply.data(), reply.size(), &resp));
   if (response_json != nullptr) *response_json = resp.Dump();
@@ -596,18 +609,18 @@ std::string NameVersion(const std::string& name, const std::string& version, con
 }
 }  // namespace
 
-Error InferenceServerGrpcClient::IsServerLive(bool* live, const Headers& headers) {
+Error InferenceServerGrpcClient::IsServerLive(bool* live, const Headers& headers, uint64_t timeout_us) {
   std::string out;
-  TCA_RETURN_IF_ERROR(JsonCall("ServerLive", "{}", headers, &out));
+  TCA_RETURN_IF_ERROR(JsonCall("ServerLive", "{}", headers, &out, timeout_us));
   json::Value v;
   TCA_RETURN_IF_ERROR(json::Parse(out.data(), out.size(), &v));
   *live = v.GetBool("live");
   return Error::Success();
 }
 
-Error InferenceServerGrpcClient::IsServerReady(bool* ready, const Headers& headers) {
+Error InferenceServerGrpcClient::IsServerReady(bool* ready, const Headers& headers, uint64_t timeout_us) {
   std::string out;
-  TCA_RETURN_IF_ERROR(JsonCall("ServerReady", "{}", headers, &out));
+  TCA_RETURN_IF_ERROR(JsonCall("ServerReady", "{}", headers, &out, timeout_us));
   json::Value v;
   TCA_RETURN_IF_ERROR(json::Parse(out.data(), out.size(), &v));
   *ready = v.GetBool("ready");
@@ -615,36 +628,36 @@ Error InferenceServerGrpcClient::IsServerReady(bool* ready, const Headers& heade
 }
 
 Error InferenceServerGrpcClient::IsModelReady(bool* ready, const std::string& model_name,
-                                              const std::string& model_version, const Headers& headers) {
+                                              const std::string& model_version, const Headers& headers, uint64_t timeout_us) {
   std::string out;
-  TCA_RETURN_IF_ERROR(JsonCall("ModelReady", NameVersion(model_name, model_version), headers, &out));
+  TCA_RETURN_IF_ERROR(JsonCall("ModelReady", NameVersion(model_name, model_version), headers, &out, timeout_us));
   json::Value v;
   TCA_RETURN_IF_ERROR(json::Parse(out.data(), out.size(), &v));
   *ready = v.GetBool("ready");
   return Error::Success();
 }
 
-Error InferenceServerGrpcClient::ServerMetadata(std::string* server_metadata, const Headers& headers) {
-  return JsonCall("ServerMetadata", "{}", headers, server_metadata);
+Error InferenceServerGrpcClient::ServerMetadata(std::string* server_metadata, const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("ServerMetadata", "{}", headers, server_metadata, timeout_us);
 }
 
 Error InferenceServerGrpcClient::ModelMetadata(std::string* model_metadata, const std::string& model_name,
-                                               const std::string& model_version, const Headers& headers) {
-  return JsonCall("ModelMetadata", NameVersion(model_name, model_version), headers, model_metadata);
+                                               const std::string& model_version, const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("ModelMetadata", NameVersion(model_name, model_version), headers, model_metadata, timeout_us);
 }
 
 Error InferenceServerGrpcClient::ModelConfig(std::string* model_config, const std::string& model_name,
-                                             const std::string& model_version, const Headers& headers) {
-  return JsonCall("ModelConfig", NameVersion(model_name, model_version), headers, model_config);
+                                             const std::string& model_version, const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("ModelConfig", NameVersion(model_name, model_version), headers, model_config, timeout_us);
 }
 
-Error InferenceServerGrpcClient::ModelRepositoryIndex(std::string* repository_index, const Headers& headers) {
-  return JsonCall("RepositoryIndex", "{}", headers, repository_index);
+Error InferenceServerGrpcClient::ModelRepositoryIndex(std::string* repository_index, const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("RepositoryIndex", "{}", headers, repository_index, timeout_us);
 }
 
 Error InferenceServerGrpcClient::LoadModel(const std::string& model_name, const Headers& headers,
                                            const std::string& config,
-                                           const std::map<std::string, std::vector<char>>& files) {
+                                           const std::map<std::string, std::vector<char>>& files, uint64_t timeout_us) {
   json::Value req = json::Value::Object();
   req["model_name"] = model_name;
   json::Value params = json::Value::Object();
@@ -659,23 +672,23 @@ Error InferenceServerGrpcClient::LoadModel(const std::string& model_name, const 
     params[kv.first] = p;
   }
   if (params.Members().size()) req["parameters"] = params;
-  return JsonCall("RepositoryModelLoad", req.Dump(), headers, nullptr);
+  return JsonCall("RepositoryModelLoad", req.Dump(), headers, nullptr, timeout_us);
 }
 
-Error InferenceServerGrpcClient::UnloadModel(const std::string& model_name, const Headers& headers) {
+Error InferenceServerGrpcClient::UnloadModel(const std::string& model_name, const Headers& headers, uint64_t timeout_us) {
   json::Value req = json::Value::Object();
   req["model_name"] = model_name;
-  return JsonCall("RepositoryModelUnload", req.Dump(), headers, nullptr);
+  return JsonCall("RepositoryModelUnload", req.Dump(), headers, nullptr, timeout_us);
 }
 
 Error InferenceServerGrpcClient::ModelInferenceStatistics(std::string* infer_stat, const std::string& model_name,
-                                                          const std::string& model_version, const Headers& headers) {
-  return JsonCall("ModelStatistics", NameVersion(model_name, model_version), headers, infer_stat);
+                                                          const std::string& model_version, const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("ModelStatistics", NameVersion(model_name, model_version), headers, infer_stat, timeout_us);
 }
 
 Error InferenceServerGrpcClient::UpdateTraceSettings(std::string* response, const std::string& model_name,
                                                      const std::map<std::string, std::vector<std::string>>& settings,
-                                                     const Headers& headers) {
+                                                     const Headers& headers, uint64_t timeout_us) {
   json::Value req = json::Value::Object();
   if (!model_name.empty()) req["model_name"] = model_name;
   json::Value s = json::Value::Object();
@@ -687,18 +700,18 @@ Error InferenceServerGrpcClient::UpdateTraceSettings(std::string* response, cons
     s[kv.first] = entry;
   }
   if (s.Members().size()) req["settings"] = s;
-  return JsonCall("TraceSetting", req.Dump(), headers, response);
+  return JsonCall("TraceSetting", req.Dump(), headers, response, timeout_us);
 }
 
 Error InferenceServerGrpcClient::GetTraceSettings(std::string* settings, const std::string& model_name,
-                                                  const Headers& headers) {
+                                                  const Headers& headers, uint64_t timeout_us) {
   json::Value req = json::Value::Object();
   if (!model_name.empty()) req["model_name"] = model_name;
-  return JsonCall("TraceSetting", req.Dump(), headers, settings);
+  return JsonCall("TraceSetting", req.Dump(), headers, settings, timeout_us);
 }
 
 Error InferenceServerGrpcClient::UpdateLogSettings(std::string* response, const std::string& settings_json,
-                                                   const Headers& headers) {
+                                                   const Headers& headers, uint64_t timeout_us) {
   // {"log_info": true, "log_verbose_level": 1, "log_format": "default"} -> typed SettingValue entries
   json::Value in;
   TCA_RETURN_IF_ERROR(json::Parse(settings_json.data(), settings_json.size(), &in));
@@ -713,49 +726,49 @@ Error InferenceServerGrpcClient::UpdateLogSettings(std::string* response, const 
   }
   json::Value req = json::Value::Object();
   if (s.Members().size()) req["settings"] = s;
-  return JsonCall("LogSettings", req.Dump(), headers, response);
+  return JsonCall("LogSettings", req.Dump(), headers, response, timeout_us);
 }
 
-Error InferenceServerGrpcClient::GetLogSettings(std::string* settings, const Headers& headers) {
-  return JsonCall("LogSettings", "{}", headers, settings);
+Error InferenceServerGrpcClient::GetLogSettings(std::string* settings, const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("LogSettings", "{}", headers, settings, timeout_us);
 }
 
 Error InferenceServerGrpcClient::SystemSharedMemoryStatus(std::string* status, const std::string& region_name,
-                                                          const Headers& headers) {
-  return JsonCall("SystemSharedMemoryStatus", NameVersion(region_name, ""), headers, status);
+                                                          const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("SystemSharedMemoryStatus", NameVersion(region_name, ""), headers, status, timeout_us);
 }
 
 Error InferenceServerGrpcClient::RegisterSystemSharedMemory(const std::string& name, const std::string& key,
-                                                            size_t byte_size, size_t offset, const Headers& headers) {
+                                                            size_t byte_size, size_t offset, const Headers& headers, uint64_t timeout_us) {
   json::Value req = json::Value::Object();
   req["name"] = name;
   req["key"] = key;
   req["offset"] = static_cast<unsigned long long>(offset);
   req["byte_size"] = static_cast<unsigned long long>(byte_size);
-  return JsonCall("SystemSharedMemoryRegister", req.Dump(), headers, nullptr);
+  return JsonCall("SystemSharedMemoryRegister", req.Dump(), headers, nullptr, timeout_us);
 }
 
-Error InferenceServerGrpcClient::UnregisterSystemSharedMemory(const std::string& name, const Headers& headers) {
-  return JsonCall("SystemSharedMemoryUnregister", NameVersion(name, ""), headers, nullptr);
+Error InferenceServerGrpcClient::UnregisterSystemSharedMemory(const std::string& name, const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("SystemSharedMemoryUnregister", NameVersion(name, ""), headers, nullptr, timeout_us);
 }
 
 Error InferenceServerGrpcClient::CudaSharedMemoryStatus(std::string* status, const std::string& region_name,
-                                                        const Headers& headers) {
-  return JsonCall("CudaSharedMemoryStatus", NameVersion(region_name, ""), headers, status);
+                                                        const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("CudaSharedMemoryStatus", NameVersion(region_name, ""), headers, status, timeout_us);
 }
 
 Error InferenceServerGrpcClient::RegisterCudaSharedMemory(const std::string& name, const void* raw_handle,
-                                                          size_t device_id, size_t byte_size, const Headers& headers) {
+                                                          size_t device_id, size_t byte_size, const Headers& headers, uint64_t timeout_us) {
   json::Value req = json::Value::Object();
   req["name"] = name;
   req["raw_handle"] = Base64Encode(raw_handle, 64);
   req["device_id"] = static_cast<long long>(device_id);
   req["byte_size"] = static_cast<unsigned long long>(byte_size);
-  return JsonCall("CudaSharedMemoryRegister", req.Dump(), headers, nullptr);
+  return JsonCall("CudaSharedMemoryRegister", req.Dump(), headers, nullptr, timeout_us);
 }
 
-Error InferenceServerGrpcClient::UnregisterCudaSharedMemory(const std::string& name, const Headers& headers) {
-  return JsonCall("CudaSharedMemoryUnregister", NameVersion(name, ""), headers, nullptr);
+Error InferenceServerGrpcClient::UnregisterCudaSharedMemory(const std::string& name, const Headers& headers, uint64_t timeout_us) {
+  return JsonCall("CudaSharedMemoryUnregister", NameVersion(name, ""), headers, nullptr, timeout_us);
 }
 
 // ---- inference ---------------------------------------------------------------------------

@@ -42,6 +42,29 @@ struct KeepAliveOptions {
   int http2_max_pings_without_data = 2;
 };
 
+// Per-channel settings beyond keep-alive: what code written against grpc++ passes as
+// grpc::ChannelArguments (reference `grpc_client.h:146-150`, `grpc_client.cc:475-498`).  Fields can be
+// set directly or through the gRPC argument names ("grpc.max_send_message_length", ...).
+struct ChannelOptions {
+  KeepAliveOptions keepalive;
+  // largest request / response message in bytes (the reference's default is INT32_MAX for both)
+  int64_t max_send_message_bytes = INT32_MAX;
+  int64_t max_receive_message_bytes = INT32_MAX;
+  // goes in front of the library's own user-agent token
+  std::string primary_user_agent;
+  // HTTP/2 receive windows and frame size advertised to the server; 0 = the library's defaults
+  uint32_t http2_stream_window_bytes = 0;
+  uint32_t http2_connection_window_bytes = 0;
+  uint32_t http2_max_frame_bytes = 0;
+
+  // By gRPC argument name.  Unknown names are an error (the reference passes them on unchecked, "at the
+  // user's own risk"; here a typo is reported instead of silently doing nothing).
+  Error SetInt(const std::string& grpc_arg, int64_t value);
+  Error SetString(const std::string& grpc_arg, const std::string& value);
+  // Everything that distinguishes two channels to the same URL (the channel cache shares only equal ones).
+  std::string CacheKey() const;
+};
+
 class GrpcChannel {
  public:
   struct CallEvents {
@@ -55,6 +78,9 @@ class GrpcChannel {
   static Error Create(std::shared_ptr<GrpcChannel>* channel, const std::string& url, bool verbose,
                       const KeepAliveOptions& keepalive = KeepAliveOptions(),
                       std::shared_ptr<net::TlsContext> tls = nullptr);
+  static Error Create(std::shared_ptr<GrpcChannel>* channel, const std::string& url, bool verbose,
+                      const ChannelOptions& options, std::shared_ptr<net::TlsContext> tls = nullptr);
+  const ChannelOptions& Options() const { return options_; }
   ~GrpcChannel();
 
   // Starts a call on "/inference.GRPCInferenceService/<method>".  Never fails
@@ -72,7 +98,7 @@ class GrpcChannel {
   const std::string& Url() const { return url_; }
 
  private:
-  GrpcChannel(std::string url, std::string host, int port, bool verbose, const KeepAliveOptions& keepalive,
+  GrpcChannel(std::string url, std::string host, int port, bool verbose, const ChannelOptions& options,
               std::shared_ptr<net::TlsContext> tls);
   struct Call {
     uint32_t stream = 0;
@@ -104,6 +130,7 @@ class GrpcChannel {
   const std::string host_;
   const int port_;
   const bool verbose_;
+  const ChannelOptions options_;
   const KeepAliveOptions keepalive_;
 
   int fd_ = -1;

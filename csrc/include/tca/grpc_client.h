@@ -43,42 +43,51 @@ class InferenceServerGrpcClient : public InferenceServerClient {
                       const KeepAliveOptions& keepalive_options = KeepAliveOptions(),
                       bool use_cached_channel = true);
 
-  Error IsServerLive(bool* live, const Headers& headers = Headers());
-  Error IsServerReady(bool* ready, const Headers& headers = Headers());
+  // The same with explicit channel settings (message size limits, user agent, keep-alive, HTTP/2 windows):
+  // what the reference takes as grpc::ChannelArguments (`grpc_client.h:146-150`).
+  static Error Create(std::unique_ptr<InferenceServerGrpcClient>* client, const std::string& server_url,
+                      const ChannelOptions& channel_options, bool verbose = false, bool use_ssl = false,
+                      const SslOptions& ssl_options = SslOptions(), bool use_cached_channel = true);
+
+  Error IsServerLive(bool* live, const Headers& headers = Headers(), uint64_t timeout_us = 0);
+  Error IsServerReady(bool* ready, const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error IsModelReady(bool* ready, const std::string& model_name, const std::string& model_version = "",
-                     const Headers& headers = Headers());
+                     const Headers& headers = Headers(), uint64_t timeout_us = 0);
+  // Every control call takes `timeout_us` last: the time the call may take, in microseconds (0 = no limit);
+  // a call that runs out of it fails with "Deadline Exceeded" (reference `grpc_client.h:157-456`, where the
+  // parameter is spelled timeout_ms and documented as microseconds).
   // The following return the response message as JSON text.
-  Error ServerMetadata(std::string* server_metadata, const Headers& headers = Headers());
+  Error ServerMetadata(std::string* server_metadata, const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error ModelMetadata(std::string* model_metadata, const std::string& model_name,
-                      const std::string& model_version = "", const Headers& headers = Headers());
+                      const std::string& model_version = "", const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error ModelConfig(std::string* model_config, const std::string& model_name, const std::string& model_version = "",
-                    const Headers& headers = Headers());
-  Error ModelRepositoryIndex(std::string* repository_index, const Headers& headers = Headers());
+                    const Headers& headers = Headers(), uint64_t timeout_us = 0);
+  Error ModelRepositoryIndex(std::string* repository_index, const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error LoadModel(const std::string& model_name, const Headers& headers = Headers(),
                   const std::string& config = std::string(),
-                  const std::map<std::string, std::vector<char>>& files = {});
-  Error UnloadModel(const std::string& model_name, const Headers& headers = Headers());
+                  const std::map<std::string, std::vector<char>>& files = {}, uint64_t timeout_us = 0);
+  Error UnloadModel(const std::string& model_name, const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error ModelInferenceStatistics(std::string* infer_stat, const std::string& model_name = "",
-                                 const std::string& model_version = "", const Headers& headers = Headers());
+                                 const std::string& model_version = "", const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error UpdateTraceSettings(std::string* response, const std::string& model_name = "",
                             const std::map<std::string, std::vector<std::string>>& settings = {},
-                            const Headers& headers = Headers());
+                            const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error GetTraceSettings(std::string* settings, const std::string& model_name = "",
-                         const Headers& headers = Headers());
+                         const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error UpdateLogSettings(std::string* response, const std::string& settings_json,
-                          const Headers& headers = Headers());
-  Error GetLogSettings(std::string* settings, const Headers& headers = Headers());
+                          const Headers& headers = Headers(), uint64_t timeout_us = 0);
+  Error GetLogSettings(std::string* settings, const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error SystemSharedMemoryStatus(std::string* status, const std::string& region_name = "",
-                                 const Headers& headers = Headers());
+                                 const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error RegisterSystemSharedMemory(const std::string& name, const std::string& key, size_t byte_size,
-                                   size_t offset = 0, const Headers& headers = Headers());
-  Error UnregisterSystemSharedMemory(const std::string& name = "", const Headers& headers = Headers());
+                                   size_t offset = 0, const Headers& headers = Headers(), uint64_t timeout_us = 0);
+  Error UnregisterSystemSharedMemory(const std::string& name = "", const Headers& headers = Headers(), uint64_t timeout_us = 0);
   // Device shared memory: `raw_handle` is the 64-byte HIP IPC handle.
   Error CudaSharedMemoryStatus(std::string* status, const std::string& region_name = "",
-                               const Headers& headers = Headers());
+                               const Headers& headers = Headers(), uint64_t timeout_us = 0);
   Error RegisterCudaSharedMemory(const std::string& name, const void* raw_handle, size_t device_id, size_t byte_size,
-                                 const Headers& headers = Headers());
-  Error UnregisterCudaSharedMemory(const std::string& name = "", const Headers& headers = Headers());
+                                 const Headers& headers = Headers(), uint64_t timeout_us = 0);
+  Error UnregisterCudaSharedMemory(const std::string& name = "", const Headers& headers = Headers(), uint64_t timeout_us = 0);
 
   Error Infer(InferResult** result, const InferOptions& options, const std::vector<InferInput*>& inputs,
               const std::vector<const InferRequestedOutput*>& outputs = {}, const Headers& headers = Headers(),
@@ -122,7 +131,7 @@ class InferenceServerGrpcClient : public InferenceServerClient {
   Error Unary(const std::string& method, const std::string& request, const Headers& headers, uint64_t timeout_us,
               std::string* response, bool compressed = false);
   Error JsonCall(const std::string& method, const std::string& request_json, const Headers& headers,
-                 std::string* response_json);
+                 std::string* response_json, uint64_t timeout_us = 0);
 
   struct StreamState;
   std::shared_ptr<GrpcChannel> channel_;

@@ -806,6 +806,65 @@ SERVER_TEST(GrpcChannelCacheAndConnectFailure) {
   EXPECT_ERROR_CONTAINS(tc::InferenceServerGrpcClient::Create(&bad, g_url, false, true, bad_ssl), "CA certificates");
 }
 
+SERVER_TEST(GrpcChannelOptionsAndControlDeadlines) {
+  // channel settings by field and by gRPC argument name
+  tc::ChannelOptions opt;
+  ASSERT_OK(opt.SetInt("grpc.max_receive_message_length", 48));
+  ASSERT_OK(opt.SetInt("grpc.keepalive_time_ms", 10000));
+  ASSERT_OK(opt.SetString("grpc.primary_user_agent", "cc-test/1"));
+  EXPECT_EQ(opt.max_receive_message_bytes, int64_t(48));
+  EXPECT_EQ(opt.keepalive.keepalive_time_ms, 10000);
+  EXPECT_ERROR_CONTAINS(opt.SetInt("grpc.no_such_argument", 1), "unsupported");
+  std::unique_ptr<tc::InferenceServerGrpcClient> small;
+  ASSERT_OK(tc::InferenceServerGrpcClient::Create(&small, g_url, opt));
+  bool live = false;
+  EXPECT_OK(small->IsServerLive(&live));  // a few bytes: fits
+  EXPECT_TRUE(live);
+  std::string text;
+  const tca::Error big = small->ModelConfig(&text, "simple");  // hundreds of bytes: refused by the client
+  EXPECT_TRUE(!big.IsOk());
+  EXPECT_EQ(big.Code(), int(tc::kGrpcResourceExhausted));
+  EXPECT_ERROR_CONTAINS(big, "Received message larger than max");
+  tc::ChannelOptions tight;
+  tight.max_send_message_bytes = 32;
+  std::unique_ptr<tc::InferenceServerGrpcClient> mute;
+  ASSERT_OK(tc::InferenceServerGrpcClient::Create(&mute, g_url, tight));
+  auto req = MakeRequest(1);
+  tc::InferResult* res = nullptr;
+  EXPECT_ERROR_CONTAINS(mute->Infer(&res, tc::InferOptions("simple"), req->inputs), "Sent message larger than max");
+  // HTTP/2 windows of a client's own choosing still move a large tensor both ways
+  tc::ChannelOptions narrow;
+  narrow.http2_stream_window_bytes = 65535;
+  narrow.http2_connection_window_bytes = 65535;
+  narrow.http2_max_frame_bytes = 16384;
+  std::unique_ptr<tc::InferenceServerGrpcClient> slow;
+  ASSERT_OK(tc::InferenceServerGrpcClient::Create(&slow, g_url, narrow, false, false, tc::SslOptions(), false));
+  std::vector<int32_t> payload(1 << 18);
+  for (size_t i = 0; i < payload.size(); ++i) payload[i] = static_cast<int32_t>(i * 7);
+  tc::InferInput* in = nullptr;
+  ASSERT_OK(tc::InferInput::Create(&in, "INPUT0", {1, static_cast<int64_t>(payload.size())}, "INT32"));
+  std::unique_ptr<tc::InferInput> in_holder(in);
+  in->AppendRaw(reinterpret_cast<const uint8_t*>(payload.data()), payload.size() * 4);
+  ASSERT_OK(slow->Infer(&res, tc::InferOptions("custom_identity_int32"), {in}));
+  std::unique_ptr<tc::InferResult> holder(res);
+  const uint8_t* buf = nullptr;
+  size_t n = 0;
+  ASSERT_OK(res->RawData("OUTPUT0", &buf, &n));
+  EXPECT_EQ(n, payload.size() * 4);
+  EXPECT_TRUE(std::memcmp(buf, payload.data(), n) == 0);
+  tc::ChannelOptions bad_frame;
+  bad_frame.http2_max_frame_bytes = 100;
+  std::unique_ptr<tc::InferenceServerGrpcClient> never;
+  EXPECT_ERROR_CONTAINS(tc::InferenceServerGrpcClient::Create(&never, g_url, bad_frame), "http2_max_frame_bytes");
+  // control calls take a deadline (microseconds); 1 us cannot be met, a second can
+  auto c = NewClient();
+  const tca::Error late = c->ServerMetadata(&text, tc::Headers(), 1);
+  EXPECT_EQ(late.Code(), int(tc::kGrpcDeadlineExceeded));
+  EXPECT_ERROR_CONTAINS(late, "Deadline Exceeded");
+  EXPECT_OK(c->ServerMetadata(&text, tc::Headers(), 1000000));
+  EXPECT_OK(c->IsModelReady(&live, "simple", "", tc::Headers(), 1000000));
+}
+
 int main(int argc, char** argv) {
   const char* filter = nullptr;
   for (int i = 1; i < argc; ++i) {

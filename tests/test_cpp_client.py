@@ -53,6 +53,18 @@ def test_cc_timeout_and_leak_tools(built, server):
     assert "PASS" in _run([os.path.join(built, "memory_leak_test"), "-u", server.http_url, "-r", "200", "-R"])
 
 
+def test_cc_timeout_and_leak_tools_grpc(built, server):
+    """The same tools over gRPC (``-i grpc``): sync, async and stream deadlines, every control call
+    under a deadline (``-p``), and the growth check with a channel per client and a shared one."""
+    tool = os.path.join(built, "client_timeout_test")
+    assert "timeouts reported" in _run([tool, "-i", "grpc", "-u", server.grpc_url, "-t", "100000"])
+    assert "requests completed" in _run([tool, "-i", "grpc", "-u", server.grpc_url, "-t", "3000000"])
+    out = _run([tool, "-i", "grpc", "-u", server.grpc_url, "-p", "-t", "1"])
+    assert "20 control calls" in out and "0 unexpected outcomes" in out and "PASS" in out
+    assert "PASS" in _run([os.path.join(built, "memory_leak_test"), "-i", "grpc", "-u", server.grpc_url, "-r", "200"])
+    assert "PASS" in _run([os.path.join(built, "memory_leak_test"), "-i", "grpc", "-u", server.grpc_url, "-r", "200", "-R"])
+
+
 def test_native_loadgen(built, server):
     import json
 
