@@ -5,6 +5,9 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <vector>
 #include <iostream>
 #include <sstream>
 
@@ -487,12 +490,36 @@ struct InferenceServerGrpcClient::StreamState {
 };
 
 // ---- client --------------------------------------------------------------------------
+struct InferenceServerGrpcClient::AsyncState {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::set<uint64_t> calls;  // started, result not delivered yet
+  int pending = 0;           // calls whose completion handler has not returned yet
+};
+
+namespace {
+// the AsyncState whose completion handler is running on this thread (a callback may destroy its client)
+thread_local const void* t_completing = nullptr;
+}  // namespace
+
 InferenceServerGrpcClient::InferenceServerGrpcClient(std::shared_ptr<GrpcChannel> channel, bool verbose)
-    : InferenceServerClient(verbose), channel_(std::move(channel)) {}
+    : InferenceServerClient(verbose), channel_(std::move(channel)), async_(std::make_shared<AsyncState>()) {}
 
 InferenceServerGrpcClient::~InferenceServerGrpcClient() {
   exiting_.store(true);
   StopStream();
+  {
+    // calls still in flight end now, as cancelled; wait until their handlers are through with this object
+    std::vector<uint64_t> open;
+    {
+      std::lock_guard<std::mutex> lk(async_->mu);
+      open.assign(async_->calls.begin(), async_->calls.end());
+    }
+    for (uint64_t id : open) channel_->Cancel(id);
+    std::unique_lock<std::mutex> lk(async_->mu);
+    const int own = t_completing == async_.get() ? 1 : 0;  // destroyed from inside one of its own callbacks
+    tca::WaitFor(async_->cv, lk, std::chrono::seconds(30), [&] { return async_->pending <= own; });
+  }
   channel_.reset();
   std::lock_guard<std::mutex> lk(g_cache_mu);
   for (auto it = g_cache.begin(); it != g_cache.end();) {
@@ -832,15 +859,36 @@ Error InferenceServerGrpcClient::AsyncInfer(OnCompleteFn callback, const InferOp
     timers->CaptureTimestamp(RequestTimers::Kind::RECV_START);
     *response = std::move(m);
   };
-  ev.on_done = [this, callback, response, timers](int status, const std::string& message) {
+  auto async = async_;
+  auto call_id = std::make_shared<uint64_t>(0);  // 0 until StartCall has returned; written and read under async->mu
+  auto finished = std::make_shared<bool>(false);
+  {
+    std::lock_guard<std::mutex> lk(async->mu);
+    ++async->pending;
+  }
+  ev.on_done = [this, async, call_id, finished, callback, response, timers](int status, const std::string& message) {
     InferResultGrpc* r = status == kGrpcOk ? InferResultGrpc::FromResponse(std::move(*response))
                                            : InferResultGrpc::FromError(StatusToError(status, message));
     timers->CaptureTimestamp(RequestTimers::Kind::RECV_END);
     timers->CaptureTimestamp(RequestTimers::Kind::REQUEST_END);
+    // `this` is alive: its destructor waits for `pending` to drain
     if (status == kGrpcOk && !exiting_.load()) UpdateInferStat(*timers);
-    callback(r);
+    const void* outer = t_completing;
+    t_completing = async.get();
+    callback(r);  // may destroy the client: nothing below touches it
+    t_completing = outer;
+    std::lock_guard<std::mutex> lk(async->mu);
+    *finished = true;
+    if (*call_id) async->calls.erase(*call_id);
+    --async->pending;
+    async->cv.notify_all();
   };
   const uint64_t call = channel_->StartCall("ModelInfer", metadata, options.client_timeout_, std::move(ev));
+  {
+    std::lock_guard<std::mutex> lk(async->mu);
+    *call_id = call;
+    if (!*finished) async->calls.insert(call);
+  }
   channel_->SendMessage(call, std::move(request), true, compressed);
   timers->CaptureTimestamp(RequestTimers::Kind::SEND_END);
   return Error::Success();

@@ -134,8 +134,13 @@ class InferenceServerGrpcClient : public InferenceServerClient {
                  std::string* response_json, uint64_t timeout_us = 0);
 
   struct StreamState;
+  struct AsyncState;
   std::shared_ptr<GrpcChannel> channel_;
   std::shared_ptr<StreamState> stream_;
+  // asynchronous calls that have not delivered their result yet: the destructor cancels them and
+  // waits for their callbacks, so none runs on a client that is gone (the channel may outlive the
+  // client: it is shared through the cache)
+  std::shared_ptr<AsyncState> async_;
 };
 
 }  // namespace client

@@ -1,5 +1,7 @@
-"""Race / memory-error detection for the native client code: the library, its
-unit tests and a multi-threaded stress test are rebuilt with
+"""Race / memory-error detection for the native code: the client library, its
+unit tests, a multi-threaded client stress test and the native gRPC serving front
+(``grpc_front_stress``: epoll reactors answered from completer threads, the serving
+benchmark's hot path, driven in-process by client threads) are rebuilt with
 ``-fsanitize=thread`` and with ``-fsanitize=address,undefined`` and run against
 the in-repo server.  (GPU code cannot run under sanitizers on this pool; these
 are host-only builds.)  The reference configures no sanitizers at all."""
@@ -10,7 +12,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TARGETS = ("stress_test", "cc_unit_test", "grpc_client_test")
+TARGETS = ("stress_test", "cc_unit_test", "grpc_client_test", "grpc_front_stress")
 
 
 def _build(kind, san):
@@ -41,3 +43,5 @@ def test_native_clients_under_sanitizer(server, kind, san, env):
     run([os.path.join(bins, "grpc_client_test"), "-u", server.grpc_url])
     r = run([os.path.join(bins, "stress_test"), "-u", server.http_url, "-g", server.grpc_url, "-n", "6", "-r", "10"])
     assert "PASS : stress" in r.stdout
+    r = run([os.path.join(bins, "grpc_front_stress"), "-n", "6", "-r", "6"])
+    assert "PASS : front stress" in r.stdout
