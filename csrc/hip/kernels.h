@@ -34,6 +34,10 @@ struct PreprocParams {
   int nhwc;      // 0: NCHW planes, 1: NHWC interleaved
   int tile_h;    // output rows per block (1..16)
   int max_rows;  // max source rows any tile needs (sizes the LDS buffer)
+  // bytes per staged source row in LDS (multiple of 4, >= widest tile's source bytes + 6), or 0: do not
+  // stage the source (pass 1 then reads it from memory)
+  int src_pitch;
+  int pad_;
   long long image_stride;  // elements between consecutive batch entries in dst
   float scale[4];
   float bias[4];

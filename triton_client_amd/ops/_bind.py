@@ -18,7 +18,8 @@ class PreprocParams(Structure):
 
     _fields_ = [
         ("out_h", c_int), ("out_w", c_int), ("out_c", c_int), ("nhwc", c_int), ("tile_h", c_int),
-        ("max_rows", c_int), ("image_stride", c_longlong), ("scale", c_float * 4), ("bias", c_float * 4),
+        ("max_rows", c_int), ("src_pitch", c_int), ("pad_", c_int), ("image_stride", c_longlong), ("scale", c_float * 4),
+        ("bias", c_float * 4),
     ]
 
 

@@ -26,6 +26,7 @@ channel) plus a general ``(mean, std)`` per channel form.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -44,6 +45,8 @@ from .preprocess_ref import (  # noqa: F401  (re-exported)
 
 TILE_W = 64
 _LDS_BUDGET = 48 * 1024
+_LDS_LIMIT = 64 * 1024  # dynamic LDS a block may ask for without opting in to more
+_STAGE_SOURCE = os.environ.get("TCA_PREPROCESS_STAGE", "1") != "0"
 
 
 # ---------------------------------------------------------------------------
@@ -84,7 +87,7 @@ class Preprocessor:
         self._dev_src = DeviceBuffer(max_image_bytes, device)
         self._desc_host = (_bind.PreprocImage * max_batch)()
         self._desc_dev = DeviceBuffer(ctypes.sizeof(self._desc_host), device)
-        self._table_cache = {}  # (h, w) -> (xb_off, yb_off, xk_off, yk_off, kx, ky, tile_h, max_rows)
+        self._table_cache = {}  # (h, w) -> (xb_off, yb_off, xk_off, yk_off, kx, ky, tile_h, max_rows, span_px)
         self._bounds_host = np.zeros((0, 2), dtype=np.int32)
         self._coeffs_host = np.zeros((0,), dtype=np.int32)
         self._bounds_dev = None
@@ -99,7 +102,7 @@ class Preprocessor:
             for oy0 in range(0, self.out_h, tile_h):
                 last = min(oy0 + tile_h, self.out_h) - 1
                 worst = max(worst, int(yb[last, 0] + yb[last, 1] - yb[oy0, 0]))
-            if worst * self.out_c * TILE_W <= _LDS_BUDGET:
+            if worst * (self.out_c * TILE_W + 4) <= _LDS_BUDGET:
                 return tile_h, worst
         raise ValueError("down-scaling factor too large for the LDS tile (source rows per output row exceed budget)")
 
@@ -111,13 +114,18 @@ class Preprocessor:
         xb, xk, kx = _tables(self.resize, w, self.out_w)
         yb, yk, ky = _tables(self.resize, h, self.out_h)
         tile_h, max_rows = self._tile_plan(yb)
+        # widest run of source columns any 64-output tile draws from (sizes the staged source rows in LDS)
+        span_px = 0
+        for ox0 in range(0, self.out_w, TILE_W):
+            last = min(ox0 + TILE_W, self.out_w) - 1
+            span_px = max(span_px, int(xb[last, 0] + xb[last, 1] - xb[ox0, 0]))
         xb_off = len(self._bounds_host)
         yb_off = xb_off + len(xb)
         xk_off = len(self._coeffs_host)
         yk_off = xk_off + xk.size
         self._bounds_host = np.concatenate([self._bounds_host, xb, yb]).astype(np.int32)
         self._coeffs_host = np.concatenate([self._coeffs_host, xk.reshape(-1), yk.reshape(-1)]).astype(np.int32)
-        entry = (xb_off, yb_off, xk_off, yk_off, kx, ky, tile_h, max_rows)
+        entry = (xb_off, yb_off, xk_off, yk_off, kx, ky, tile_h, max_rows, span_px)
         self._table_cache[key] = entry
         self._tables_dirty = True
         return entry
@@ -156,7 +164,7 @@ class Preprocessor:
         sh = stream_handle(use_stream)
         L = lib()
         cursor = 0
-        tile_h, max_rows = 16, 1
+        tile_h, max_rows, span_bytes = 16, 1, 0
         host_chunks = []
         for i, im in enumerate(images):
             on_device = hasattr(im, "data_ptr")
@@ -165,8 +173,9 @@ class Preprocessor:
             c = 1 if len(shape) == 2 else int(shape[2])
             if c not in (1, 3, 4):
                 raise ValueError(f"image {i}: unsupported channel count {c}")
-            xb_off, yb_off, xk_off, yk_off, kx, ky, th, mr = self._entry(h, w)
+            xb_off, yb_off, xk_off, yk_off, kx, ky, th, mr, span_px = self._entry(h, w)
             tile_h = min(tile_h, th)
+            span_bytes = max(span_bytes, span_px * c)
             d = self._desc_host[i]
             if on_device:
                 if not im.is_contiguous():
@@ -189,7 +198,7 @@ class Preprocessor:
         # tile height must suit every image of the batch: recompute rows for the chosen height
         for im in images:
             h = int(im.shape[0])
-            _, yb_off, _, _, _, _, th, mr = self._table_cache[(h, int(im.shape[1]))]
+            _, yb_off, _, _, _, _, th, mr, _ = self._table_cache[(h, int(im.shape[1]))]
             if th == tile_h:
                 max_rows = max(max_rows, mr)
             else:
@@ -206,6 +215,13 @@ class Preprocessor:
         prm.out_h, prm.out_w, prm.out_c = self.out_h, self.out_w, self.out_c
         prm.nhwc = 1 if self.nhwc else 0
         prm.tile_h, prm.max_rows = tile_h, max_rows
+        # staged source rows: widest tile's bytes in whole dwords; an odd dword pitch keeps the rows of one
+        # byte column on different LDS banks
+        pitch = ((span_bytes + 3) // 4) | 1
+        if _STAGE_SOURCE and max_rows * (self.out_c * TILE_W + 4 + pitch * 4) <= _LDS_LIMIT:
+            prm.src_pitch = pitch * 4
+        else:
+            prm.src_pitch = 0
         prm.image_stride = self.image_elems
         for c in range(4):
             prm.scale[c] = self.scale[c]
