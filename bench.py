@@ -59,7 +59,11 @@ def parse_args():
                     help="native: C++ load generator (tca_loadgen) over the in-tree gRPC/HTTP client; "
                          "python: tritonclient-API threads in this process")
     ap.add_argument("--connections", type=int, default=4, help="gRPC channels the native load generator spreads over")
-    ap.add_argument("--mode", choices=["serve", "fanout"], default="serve",
+    ap.add_argument("--image-requests", type=int, default=3000,
+                    help="requests of the end-to-end image pipeline run (extra.image_client)")
+    ap.add_argument("--image-lanes", type=int, default=3)
+    ap.add_argument("--image-depth", type=int, default=6)
+    ap.add_argument("--mode", choices=["serve", "fanout", "image_client"], default="serve",
                     help="fanout: also measure resnet50_sharded (one request's batch split over the GPUs), "
                          "reported under extra.fanout; runs by itself when there are several ranks")
     ap.add_argument("--fanout-devices", default=None,
@@ -384,6 +388,33 @@ def measure(args, url, device, dist, label):
     }
 
 
+def measure_image_client(args, url, device):
+    """The image client's whole loop, pipelined: decoded u8 images (480x640) in page-locked
+    memory -> host-to-device copy + fused HIP preprocess -> slot of a HIP shared-memory region
+    -> async gRPC request for the top-3 classes -> response.  Image decode is outside the
+    timed part; everything else a classification client does per image is inside."""
+    import numpy as np
+
+    from triton_client_amd.pipeline import ImagePipeline
+
+    rng = np.random.default_rng(99 + device)
+    batches = [[rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8) for _ in range(args.batch)] for _ in range(4)]
+    pipe = ImagePipeline(url, args.model, batch=args.batch, lanes=args.image_lanes, depth=args.image_depth,
+                         classes=3, device=device)
+    try:
+        pipe.pin(batches)
+        pipe.run(max(64, args.image_requests // 8))  # warm-up: graphs for the slots' addresses, channels
+        r = pipe.run(args.image_requests, keep_results=1)
+        top = [e.decode() for e in r["results"][0].as_numpy(pipe.output_name).reshape(-1)[:3]]
+        return {"images_per_sec": round(r["images_per_sec"], 1), "requests": r["requests"], "batch": args.batch,
+                "elapsed_s": round(r["elapsed_s"], 4), "p50_latency_us": round(r["p50_us"], 1),
+                "p99_latency_us": round(r["p99_us"], 1), "lanes": args.image_lanes, "slots_per_lane": args.image_depth,
+                "source": "480x640x3 u8 in pinned host memory", "client": "Python (tritonclient.grpc async_infer)",
+                "first_result_top3": top}
+    finally:
+        pipe.close()
+
+
 def measure_fanout(args, world):
     """``resnet50_sharded`` on GPU 0 with one replica process per further GPU: requests of
     ``32 x replicas`` images in HIP shared memory, split over the replicas and gathered into
@@ -502,7 +533,7 @@ def main():
             # the same requests with the tensors inside the messages / in system shared memory:
             # short runs, same server, same generator, same concurrency
             for key, mode in (("wire", "none"), ("system_shm", "system")):
-                if mode == args.shared_memory:
+                if mode == args.shared_memory or args.mode == "image_client":
                     continue
                 r = measure_native(args, url, device, dist, f"{args.protocol}+{mode}", mode=mode, steps=1,
                                    per_step=args.extra_requests, warmup_requests=max(64, args.extra_requests // 8))
@@ -510,6 +541,11 @@ def main():
                                "p99_latency_us": round(r["p99_us"], 1), "requests": r["requests"],
                                "elapsed_s": round(r["elapsed_s"], 4)}
                 extras[key]["main_over_this"] = round(main_result["infer_per_sec"] / r["infer_per_sec"], 3)
+            if args.protocol == "grpc" and (args.mode == "image_client" or world == 1):
+                try:
+                    extras["image_client"] = measure_image_client(args, url, device)
+                except BaseException as e:  # noqa: BLE001 - the headline number must survive
+                    extras["image_client"] = {"error": f"{type(e).__name__}: {e}"[:500]}
     finally:
         server.stop()
     if dist is not None:

@@ -116,23 +116,40 @@ def batches(items, batch_size):
 
 
 class HipInputStage:
-    """Owns a HIP preprocessor and a device shared-memory region sized for one
-    batch; ``fill`` runs the fused kernel with the region as destination."""
+    """Owns a HIP preprocessor and ONE device shared-memory region cut into
+    ``depth`` batch-sized slots.  ``fill`` runs the fused kernel with a free slot
+    as destination, so batch k+1 is preprocessed while the server still reads
+    batch k; the caller hands a slot back with ``release`` once the response
+    of the request that used it has arrived."""
 
-    def __init__(self, client, spec, scaling, batch_size, device=0, name="image_input"):
+    def __init__(self, client, spec, scaling, batch_size, device=0, name="image_input", depth=4):
         import tritonclient.utils.cuda_shared_memory as hipshm
         from triton_client_amd.ops.preprocess import Preprocessor
 
         self._hipshm, self._client, self._name = hipshm, client, name
         self.pre = Preprocessor(spec.h, spec.w, spec.c, spec.layout, spec.dtype, scaling, "pil", device=device,
                                 max_batch=batch_size)
-        self.nbytes = self.pre.image_bytes * batch_size
+        self.depth = max(1, int(depth))
+        self.slot_bytes = self.pre.image_bytes * batch_size
+        self.nbytes = self.slot_bytes * self.depth
+        self._free = list(range(self.depth))
         self.region = hipshm.create_shared_memory_region(name, self.nbytes, device)
         client.register_cuda_shared_memory(name, hipshm.get_raw_handle(self.region), device, self.nbytes)
 
+    def has_free_slot(self):
+        return bool(self._free)
+
     def fill(self, images):
-        self.pre(images, self.region)
-        return self._name, self.pre.image_bytes * len(images)
+        """Preprocesses ``images`` into a free slot; returns (region name, byte size, offset, slot)."""
+        if not self._free:
+            raise RuntimeError("every slot of the input ring is still in flight")
+        slot = self._free.pop(0)
+        offset = slot * self.slot_bytes
+        self.pre(images, self.region, out_offset=offset)  # synchronises: the server reads from another process
+        return self._name, self.pre.image_bytes * len(images), offset, slot
+
+    def release(self, slot):
+        self._free.append(slot)
 
     def close(self):
         self._client.unregister_cuda_shared_memory(self._name)

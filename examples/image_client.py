@@ -33,6 +33,8 @@ if __name__ == "__main__":
     ap.add_argument("--preprocess", choices=["host", "hip"], default="host",
                     help="host: numpy/Pillow on the CPU; hip: fused kernel into device shared memory")
     ap.add_argument("-g", "--device", type=int, default=0, help="GPU ordinal for --preprocess hip")
+    ap.add_argument("--ring-depth", type=int, default=4,
+                    help="--preprocess hip: batch slots in the input region (requests in flight while the next is filled)")
     ap.add_argument("image_filename", nargs="?", default=None, help="Input image / input folder")
     flags = ap.parse_args()
     grpc_mode = flags.protocol.lower() == "grpc"
@@ -56,25 +58,38 @@ if __name__ == "__main__":
 
     filenames = list_images(flags.image_filename)
     pixels = [decode(f, spec.c) for f in filenames]
-    stage = HipInputStage(client, spec, flags.scaling, flags.batch_size, flags.device) \
+    stage = HipInputStage(client, spec, flags.scaling, flags.batch_size, flags.device, depth=flags.ring_depth) \
         if flags.preprocess == "hip" else None
     tensors = None if stage else [host_preprocess(p, spec, flags.scaling) for p in pixels]
 
     done = queue.Queue()
     responses, pending, sent_names = [], [], []
     callbacks_outstanding = 0
+    slot_of = {}  # request id -> ring slot its input occupies
 
-    def drain():
-        """Waits for every request sent so far."""
+    def request_id(r):
+        raw = r.get_response()
+        return raw["id"] if isinstance(raw, dict) else raw.id
+
+    def collect_one():
+        """Waits for one outstanding request (the oldest future, or whichever callback fires next)
+        and frees the ring slot its input used."""
         global callbacks_outstanding
-        while pending:
-            responses.append(pending.pop(0).get_result())
-        while callbacks_outstanding:
+        if pending:
+            result = pending.pop(0).get_result()
+        else:
             result, error = done.get(timeout=60)
             callbacks_outstanding -= 1
             if error is not None:
                 fail("inference failed: " + str(error))
-            responses.append(result)
+        responses.append(result)
+        slot = slot_of.pop(request_id(result), None)
+        if slot is not None:
+            stage.release(slot)
+
+    def drain():
+        while pending or callbacks_outstanding:
+            collect_one()
 
     if flags.streaming:
         client.start_stream(partial(completion, done))
@@ -83,9 +98,11 @@ if __name__ == "__main__":
         for sent, batch in enumerate(batches(filenames, flags.batch_size), start=1):
             inp = mod.InferInput(spec.input_name, ([len(batch)] if batched else []) + dims, spec.dtype)
             if stage:
-                drain()  # one region: the next fill must not overtake a request still reading it
-                region, nbytes = stage.fill([pixels[i] for i in batch])
-                inp.set_shared_memory(region, nbytes)
+                while not stage.has_free_slot():  # ring full: the oldest request still reads its slot
+                    collect_one()
+                region, nbytes, offset, slot = stage.fill([pixels[i] for i in batch])
+                inp.set_shared_memory(region, nbytes, offset=offset)
+                slot_of[str(sent)] = slot
             else:
                 inp.set_data_from_numpy(np.stack([tensors[i] for i in batch]) if batched else tensors[batch[0]])
             out = mod.InferRequestedOutput(spec.output_name, class_count=flags.classes)
@@ -101,16 +118,14 @@ if __name__ == "__main__":
                 pending.append(client.async_infer(flags.model_name, [inp], **kwargs))
             else:
                 responses.append(client.infer(flags.model_name, [inp], **kwargs))
+                if stage:
+                    stage.release(slot_of.pop(str(sent)))
         drain()
     except InferenceServerException as e:
         fail("inference failed: " + str(e))
     finally:
         if flags.streaming:
             client.stop_stream()
-
-    def request_id(r):
-        raw = r.get_response()
-        return raw["id"] if isinstance(raw, dict) else raw.id
 
     for response in sorted(responses, key=lambda r: int(request_id(r))):
         rid = request_id(response)

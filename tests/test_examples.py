@@ -205,3 +205,15 @@ def test_image_client_hip_preprocess_matches_host(live, images):
     dev = run_example("image_client.py", *common, "--preprocess", "hip", images)
     pick = lambda text: [line.split(" (")[1] for line in text.splitlines() if line.startswith("    ")]  # noqa: E731
     assert pick(host) == pick(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [("-a",), ("--streaming",)])
+def test_image_client_hip_ring_keeps_requests_in_flight(live, images, mode):
+    """More requests than ring slots: a slot is refilled only after the response of the request
+    that used it, and the classes still match the host pipeline."""
+    common = ["-u", live.grpc_url, "-i", "grpc", "-m", "tiny_classifier", "-b", "1", "-c", "2", "-s", "INCEPTION"]
+    host = run_example("image_client.py", *common, images)
+    dev = run_example("image_client.py", *common, *mode, "--preprocess", "hip", "--ring-depth", "2", images)
+    pick = lambda text: [line.split(" (")[1] for line in text.splitlines() if line.startswith("    ")]  # noqa: E731
+    assert pick(host) == pick(dev) and len(pick(dev)) == 6

@@ -303,3 +303,40 @@ def test_bf16_region_from_gpu_and_host_tensors(hipshm, round_nearest):
         assert rel.max() <= (2.0 ** -8 if round_nearest else 2.0 ** -7)
     finally:
         hipshm.destroy_shared_memory_region(h)
+
+
+def test_image_pipeline_matches_one_request_at_a_time(hipshm, gpu_server):
+    """Pinned images -> HIP preprocess -> region slots -> async gRPC (top-k), several requests
+    in flight over two lanes: every response equals the classes of the same batch sent the
+    plain way (preprocessed into a tensor, tensor on the wire)."""
+    import torch
+    import tritonclient.grpc as mod
+
+    from triton_client_amd.ops.preprocess import Preprocessor
+    from triton_client_amd.pipeline import ImagePipeline
+
+    rng = np.random.default_rng(7)
+    batches = [[rng.integers(0, 256, size=(240 + 16 * k, 320, 3), dtype=np.uint8) for _ in range(4)] for k in range(3)]
+    pre = Preprocessor(224, 224, 3, "NCHW", "FP16", "INCEPTION", "pil", device=0, max_batch=4)
+    expected = []
+    with mod.InferenceServerClient(gpu_server.grpc_url) as c:
+        for images in batches:
+            x = torch.empty(4, 3, 224, 224, dtype=torch.float16, device="cuda:0")
+            pre(images, x)
+            inp = mod.InferInput("input", [4, 3, 224, 224], "FP16")
+            inp.set_data_from_numpy(x.cpu().numpy())
+            r = c.infer("resnet50", [inp], outputs=[mod.InferRequestedOutput("output", class_count=3)])
+            expected.append([e.decode().split(":")[1] for e in r.as_numpy("output").reshape(-1)])
+    pre.close()
+    pipe = ImagePipeline(gpu_server.grpc_url, "resnet50", batch=4, lanes=2, depth=2, classes=3, device=0)
+    try:
+        pipe.pin(batches)
+        out = pipe.run(18, keep_results=18)
+        assert out["requests"] == 18 and out["images"] == 72 and len(out["results"]) == 18
+        for r in out["results"]:
+            got = [e.decode().split(":")[1] for e in r.as_numpy("output").reshape(-1)]
+            assert got in expected
+        seen = {tuple(e.decode().split(":")[1] for e in r.as_numpy("output").reshape(-1)) for r in out["results"]}
+        assert len(seen) == len({tuple(e) for e in expected})
+    finally:
+        pipe.close()

@@ -164,7 +164,7 @@ class Preprocessor:
         sh = stream_handle(use_stream)
         L = lib()
         cursor = 0
-        tile_h, max_rows, span_bytes = 16, 1, 0
+        tile_h, span_bytes = 16, 0
         host_chunks = []
         for i, im in enumerate(images):
             on_device = hasattr(im, "data_ptr")
@@ -196,21 +196,21 @@ class Preprocessor:
             d.kx, d.ky = kx, ky
             d.xb_off, d.yb_off, d.xk_off, d.yk_off = xb_off, yb_off, xk_off, yk_off
         # tile height must suit every image of the batch: recompute rows for the chosen height
-        for im in images:
-            h = int(im.shape[0])
-            _, yb_off, _, _, _, _, th, mr, _ = self._table_cache[(h, int(im.shape[1]))]
-            if th == tile_h:
-                max_rows = max(max_rows, mr)
-            else:
-                yb = self._bounds_host[yb_off: yb_off + self.out_h]
-                for oy0 in range(0, self.out_h, tile_h):
-                    last = min(oy0 + tile_h, self.out_h) - 1
-                    max_rows = max(max_rows, int(yb[last, 0] + yb[last, 1] - yb[oy0, 0]))
+        max_rows = self._rows_for([(int(im.shape[0]), int(im.shape[1])) for im in images], tile_h)
         self._sync_tables()
         if cursor:
             check(L.tca_hip_memcpy_async(self._dev_src.ptr, self._pinned.ptr, cursor, 1, sh), "image upload")
         check(L.tca_hip_memcpy_async(self._desc_dev.ptr, ctypes.addressof(self._desc_host),
                                      ctypes.sizeof(_bind.PreprocImage) * n, 1, sh), "descriptor upload")
+        prm = self._params(tile_h, max_rows, span_bytes)
+        rc = L.tca_preprocess_launch(self._desc_dev.ptr, self._bounds_dev.ptr, self._coeffs_dev.ptr,
+                                     as_pointer(out, out_offset), ctypes.byref(prm), n,
+                                     _bind.DTYPE_CODE[self.dtype], sh)
+        check(rc, "tca_preprocess_launch")
+        if synchronize:
+            check(L.tca_hip_stream_sync(sh), "hipStreamSynchronize")
+
+    def _params(self, tile_h, max_rows, span_bytes):
         prm = _bind.PreprocParams()
         prm.out_h, prm.out_w, prm.out_c = self.out_h, self.out_w, self.out_c
         prm.nhwc = 1 if self.nhwc else 0
@@ -226,8 +226,40 @@ class Preprocessor:
         for c in range(4):
             prm.scale[c] = self.scale[c]
             prm.bias[c] = self.bias[c]
+        return prm
+
+    def _rows_for(self, shapes, tile_h):
+        """Largest source-row span of a ``tile_h`` tall tile over images of ``shapes`` [(h, w), ...]."""
+        max_rows = 1
+        for h, w in shapes:
+            _, yb_off, _, _, _, _, th, mr, _ = self._table_cache[(h, w)]
+            if th == tile_h:
+                max_rows = max(max_rows, mr)
+            else:
+                yb = self._bounds_host[yb_off: yb_off + self.out_h]
+                for oy0 in range(0, self.out_h, tile_h):
+                    last = min(oy0 + tile_h, self.out_h) - 1
+                    max_rows = max(max_rows, int(yb[last, 0] + yb[last, 1] - yb[oy0, 0]))
+        return max_rows
+
+    def pin(self, images, bgr=False):
+        """Copies decoded ``images`` (HWC / HW uint8 numpy arrays) once into page-locked memory and
+        prepares their descriptors: running the returned ``PinnedBatch`` costs one host-to-device
+        copy and one launch, with no per-image work on the host."""
+        return PinnedBatch(self, images, bgr)
+
+    def run_pinned(self, batch, out, out_offset=0, stream=None, synchronize=True):
+        """Preprocesses a ``PinnedBatch`` of this preprocessor into ``out`` (see ``__call__``)."""
+        if batch.owner is not self:
+            raise ValueError("the batch was pinned for another Preprocessor")
+        sh = stream_handle(self._stream if stream is None else stream)
+        L = lib()
+        self._sync_tables()
+        check(L.tca_hip_memcpy_async(self._dev_src.ptr, batch.pinned.ptr, batch.nbytes, 1, sh), "image upload")
+        check(L.tca_hip_memcpy_async(self._desc_dev.ptr, ctypes.addressof(batch.desc), ctypes.sizeof(batch.desc), 1, sh),
+              "descriptor upload")
         rc = L.tca_preprocess_launch(self._desc_dev.ptr, self._bounds_dev.ptr, self._coeffs_dev.ptr,
-                                     as_pointer(out, out_offset), ctypes.byref(prm), n,
+                                     as_pointer(out, out_offset), ctypes.byref(batch.params), batch.count,
                                      _bind.DTYPE_CODE[self.dtype], sh)
         check(rc, "tca_preprocess_launch")
         if synchronize:
@@ -239,3 +271,46 @@ class Preprocessor:
             if buf is not None:
                 buf.close()
         self._stream.close()
+
+
+class PinnedBatch:
+    """Decoded images of one batch in page-locked memory plus everything a launch needs
+    (descriptors with their staging addresses, tile plan).  Built by ``Preprocessor.pin``."""
+
+    def __init__(self, owner, images, bgr=False):
+        n = len(images)
+        if n == 0 or n > owner.max_batch:
+            raise ValueError(f"batch of {n} images (max_batch={owner.max_batch})")
+        self.owner, self.count = owner, n
+        self.desc = (_bind.PreprocImage * n)()
+        offsets, cursor = [], 0
+        for im in images:
+            cursor = (cursor + 15) & ~15
+            offsets.append(cursor)
+            cursor += int(np.asarray(im).size)
+        if cursor > owner._dev_src.nbytes:
+            raise ValueError("batch does not fit the staging buffer; raise max_image_bytes")
+        self.nbytes = cursor
+        self.pinned = PinnedBuffer(cursor)
+        tile_h, span_bytes, shapes = 16, 0, []
+        for i, im in enumerate(images):
+            arr = np.ascontiguousarray(im, dtype=np.uint8)
+            h, w = int(arr.shape[0]), int(arr.shape[1])
+            c = 1 if arr.ndim == 2 else int(arr.shape[2])
+            if c not in (1, 3, 4):
+                raise ValueError(f"image {i}: unsupported channel count {c}")
+            xb_off, yb_off, xk_off, yk_off, kx, ky, th, _, span_px = owner._entry(h, w)
+            tile_h = min(tile_h, th)
+            span_bytes = max(span_bytes, span_px * c)
+            shapes.append((h, w))
+            self.pinned.array[offsets[i]: offsets[i] + arr.size] = arr.reshape(-1)
+            d = self.desc[i]
+            d.src = owner._dev_src.ptr + offsets[i]
+            d.height, d.width, d.stride, d.channels = h, w, w * c, c
+            d.bgr = 1 if (bgr and c >= 3) else 0
+            d.kx, d.ky = kx, ky
+            d.xb_off, d.yb_off, d.xk_off, d.yk_off = xb_off, yb_off, xk_off, yk_off
+        self.params = owner._params(tile_h, owner._rows_for(shapes, tile_h), span_bytes)
+
+    def close(self):
+        self.pinned.close()
