@@ -1,0 +1,230 @@
+#include "tca/image_io.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+
+namespace tca {
+namespace {
+
+uint32_t Be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+
+struct PngHeader {
+  uint32_t width = 0, height = 0;
+  int depth = 0, color = 0, interlace = 0;
+  int Samples() const { return color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : 4; }
+  size_t RowBytes(uint32_t w) const { return (static_cast<size_t>(w) * Samples() * depth + 7) / 8; }
+};
+
+int Paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// Reverses the scanline filters of one (sub-)image in place; `raw` holds h rows of 1 + row_bytes.
+Error Unfilter(uint8_t* raw, uint32_t h, size_t row_bytes, size_t bpp) {
+  const size_t pitch = row_bytes + 1;
+  for (uint32_t y = 0; y < h; ++y) {
+    uint8_t* cur = raw + y * pitch + 1;
+    const uint8_t* up = y ? cur - pitch : nullptr;
+    switch (cur[-1]) {
+      case 0: break;
+      case 1:
+        for (size_t i = bpp; i < row_bytes; ++i) cur[i] = static_cast<uint8_t>(cur[i] + cur[i - bpp]);
+        break;
+      case 2:
+        if (up) for (size_t i = 0; i < row_bytes; ++i) cur[i] = static_cast<uint8_t>(cur[i] + up[i]);
+        break;
+      case 3:
+        for (size_t i = 0; i < row_bytes; ++i) {
+          const int left = i >= bpp ? cur[i - bpp] : 0, above = up ? up[i] : 0;
+          cur[i] = static_cast<uint8_t>(cur[i] + ((left + above) >> 1));
+        }
+        break;
+      case 4:
+        for (size_t i = 0; i < row_bytes; ++i) {
+          const int left = i >= bpp ? cur[i - bpp] : 0, above = up ? up[i] : 0, corner = (up && i >= bpp) ? up[i - bpp] : 0;
+          cur[i] = static_cast<uint8_t>(cur[i] + Paeth(left, above, corner));
+        }
+        break;
+      default: return Error("PNG: unknown scanline filter " + std::to_string(cur[-1]));
+    }
+  }
+  return Error::Success();
+}
+
+// Sample `index` of a packed row, scaled to 8 bits (palette indices are returned as they are).
+inline uint8_t Sample(const uint8_t* row, size_t index, int depth, bool scale) {
+  if (depth == 8) return row[index];
+  if (depth == 16) return row[index * 2];
+  const size_t bit = index * depth;
+  const int v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+  return static_cast<uint8_t>(scale ? v * 255 / ((1 << depth) - 1) : v);
+}
+
+}  // namespace
+
+Error DecodePng(const uint8_t* data, size_t size, DecodedImage* out) {
+  static const uint8_t kSignature[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+  if (size < 8 || std::memcmp(data, kSignature, 8) != 0) return Error("PNG: bad signature");
+  PngHeader hdr;
+  bool have_header = false, done = false;
+  std::vector<uint8_t> palette, compressed;
+  size_t pos = 8;
+  while (!done) {
+    if (pos + 12 > size) return Error("PNG: truncated file");
+    const uint32_t len = Be32(data + pos);
+    const uint8_t* type = data + pos + 4;
+    if (len > size - pos - 12) return Error("PNG: chunk runs past the end of the file");
+    const uint8_t* body = type + 4;
+    if (static_cast<uint32_t>(crc32(crc32(0L, Z_NULL, 0), type, len + 4)) != Be32(body + len))
+      return Error("PNG: checksum mismatch in chunk " + std::string(reinterpret_cast<const char*>(type), 4));
+    if (!have_header && std::memcmp(type, "IHDR", 4) != 0) return Error("PNG: first chunk is not IHDR");
+    if (std::memcmp(type, "IHDR", 4) == 0) {
+      if (len != 13) return Error("PNG: bad IHDR");
+      hdr.width = Be32(body);
+      hdr.height = Be32(body + 4);
+      hdr.depth = body[8];
+      hdr.color = body[9];
+      hdr.interlace = body[12];
+      const bool depth_ok = hdr.color == 0 ? (hdr.depth == 1 || hdr.depth == 2 || hdr.depth == 4 || hdr.depth == 8 || hdr.depth == 16)
+                            : hdr.color == 3 ? (hdr.depth == 1 || hdr.depth == 2 || hdr.depth == 4 || hdr.depth == 8)
+                            : (hdr.color == 2 || hdr.color == 4 || hdr.color == 6) ? (hdr.depth == 8 || hdr.depth == 16)
+                                                                                   : false;
+      if (!depth_ok || body[10] != 0 || body[11] != 0 || hdr.interlace > 1) return Error("PNG: unsupported header");
+      if (hdr.width == 0 || hdr.height == 0 || hdr.width > (1u << 16) || hdr.height > (1u << 16))
+        return Error("PNG: unsupported dimensions");
+      have_header = true;
+    } else if (std::memcmp(type, "PLTE", 4) == 0) {
+      if (len % 3 != 0 || len > 768) return Error("PNG: bad palette");
+      palette.assign(body, body + len);
+    } else if (std::memcmp(type, "IDAT", 4) == 0) {
+      compressed.insert(compressed.end(), body, body + len);
+    } else if (std::memcmp(type, "IEND", 4) == 0) {
+      done = true;
+    }
+    pos += 12 + len;
+  }
+  if (hdr.color == 3 && palette.empty()) return Error("PNG: palette image without a palette");
+
+  // the passes of an image: one for a plain file, Adam7's seven otherwise
+  struct Pass { uint32_t x0, y0, dx, dy; };
+  static const Pass kAdam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  static const Pass kWhole = {0, 0, 1, 1};
+  const Pass* passes = hdr.interlace ? kAdam7 : &kWhole;
+  const int pass_count = hdr.interlace ? 7 : 1;
+  size_t raw_size = 0;
+  for (int p = 0; p < pass_count; ++p) {
+    const uint32_t w = (hdr.width - passes[p].x0 + passes[p].dx - 1) / passes[p].dx;
+    const uint32_t h = (hdr.height - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
+    if (passes[p].x0 < hdr.width && passes[p].y0 < hdr.height) raw_size += static_cast<size_t>(h) * (1 + hdr.RowBytes(w));
+  }
+  std::vector<uint8_t> raw(raw_size);
+  uLongf got = static_cast<uLongf>(raw_size);
+  const int zrc = uncompress(raw.data(), &got, compressed.data(), static_cast<uLong>(compressed.size()));
+  if (zrc != Z_OK || got != raw_size) return Error("PNG: image data does not inflate to the size the header implies");
+
+  const bool gray = hdr.color == 0 || hdr.color == 4;
+  out->height = static_cast<int>(hdr.height);
+  out->width = static_cast<int>(hdr.width);
+  out->channels = gray ? 1 : 3;
+  out->pixels.assign(static_cast<size_t>(hdr.height) * hdr.width * out->channels, 0);
+  const int samples = hdr.Samples();
+  const size_t bpp = std::max<size_t>(1, static_cast<size_t>(samples) * hdr.depth / 8);
+  uint8_t* cursor = raw.data();
+  for (int p = 0; p < pass_count; ++p) {
+    const Pass& ps = passes[p];
+    if (ps.x0 >= hdr.width || ps.y0 >= hdr.height) continue;
+    const uint32_t w = (hdr.width - ps.x0 + ps.dx - 1) / ps.dx;
+    const uint32_t h = (hdr.height - ps.y0 + ps.dy - 1) / ps.dy;
+    const size_t row_bytes = hdr.RowBytes(w);
+    TCA_RETURN_IF_ERROR(Unfilter(cursor, h, row_bytes, bpp));
+    for (uint32_t y = 0; y < h; ++y) {
+      const uint8_t* row = cursor + y * (row_bytes + 1) + 1;
+      uint8_t* dst_row = out->pixels.data() + static_cast<size_t>(ps.y0 + y * ps.dy) * hdr.width * out->channels;
+      for (uint32_t x = 0; x < w; ++x) {
+        uint8_t* dst = dst_row + static_cast<size_t>(ps.x0 + x * ps.dx) * out->channels;
+        if (hdr.color == 3) {
+          const size_t idx = Sample(row, x, hdr.depth, false);
+          if (idx * 3 + 2 >= palette.size()) return Error("PNG: palette index out of range");
+          dst[0] = palette[idx * 3];
+          dst[1] = palette[idx * 3 + 1];
+          dst[2] = palette[idx * 3 + 2];
+        } else if (gray) {
+          dst[0] = Sample(row, static_cast<size_t>(x) * samples, hdr.depth, true);
+        } else {
+          for (int c = 0; c < 3; ++c) dst[c] = Sample(row, static_cast<size_t>(x) * samples + c, hdr.depth, true);
+        }
+      }
+    }
+    cursor += static_cast<size_t>(h) * (row_bytes + 1);
+  }
+  return Error::Success();
+}
+
+Error DecodePnm(const uint8_t* data, size_t size, DecodedImage* out) {
+  if (size < 2 || data[0] != 'P' || (data[1] != '5' && data[1] != '6')) return Error("PNM: binary PGM (P5) or PPM (P6) expected");
+  size_t pos = 2;
+  auto next_int = [&](int* value) {
+    for (;;) {
+      while (pos < size && std::isspace(data[pos])) ++pos;
+      if (pos < size && data[pos] == '#') {
+        while (pos < size && data[pos] != '\n') ++pos;
+        continue;
+      }
+      break;
+    }
+    if (pos >= size || !std::isdigit(data[pos])) return false;
+    long v = 0;
+    while (pos < size && std::isdigit(data[pos]) && v < (1 << 24)) v = v * 10 + (data[pos++] - '0');
+    *value = static_cast<int>(v);
+    return true;
+  };
+  int w = 0, h = 0, maxval = 0;
+  if (!next_int(&w) || !next_int(&h) || !next_int(&maxval)) return Error("PNM: bad header");
+  if (w <= 0 || h <= 0 || w > (1 << 16) || h > (1 << 16) || maxval != 255) return Error("PNM: unsupported geometry or maxval");
+  ++pos;  // the single whitespace byte after maxval
+  const int c = data[1] == '6' ? 3 : 1;
+  const size_t need = static_cast<size_t>(w) * h * c;
+  if (pos > size || size - pos < need) return Error("PNM: truncated pixel data");
+  out->height = h;
+  out->width = w;
+  out->channels = c;
+  out->pixels.assign(data + pos, data + pos + need);
+  return Error::Success();
+}
+
+Error ReadImageFile(const std::string& path, DecodedImage* out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return Error("unable to open '" + path + "'");
+  std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  if (bytes.size() >= 2 && bytes[0] == 0x89 && bytes[1] == 'P') return DecodePng(bytes.data(), bytes.size(), out);
+  if (bytes.size() >= 2 && bytes[0] == 'P') return DecodePnm(bytes.data(), bytes.size(), out);
+  return Error("'" + path + "': not a PNG or binary PNM file");
+}
+
+void ConvertChannels(const DecodedImage& in, int channels, DecodedImage* out) {
+  out->height = in.height;
+  out->width = in.width;
+  out->channels = channels;
+  const size_t n = static_cast<size_t>(in.height) * in.width;
+  out->pixels.resize(n * channels);
+  if (in.channels == channels) {
+    out->pixels = in.pixels;
+  } else if (channels == 1) {
+    for (size_t i = 0; i < n; ++i) {
+      const uint8_t* p = &in.pixels[i * in.channels];
+      out->pixels[i] = static_cast<uint8_t>((p[0] * 19595u + p[1] * 38470u + p[2] * 7471u + 0x8000u) >> 16);
+    }
+  } else {
+    for (size_t i = 0; i < n; ++i)
+      for (int c = 0; c < channels; ++c) out->pixels[i * channels + c] = in.pixels[i];
+  }
+}
+
+}  // namespace tca

@@ -1,21 +1,36 @@
-// Image classification client (HTTP): reads the model's metadata + config to
-// learn its input layout / type, preprocesses images on the CPU (2-tap bilinear
-// resize as cv::resize does, NONE / VGG / INCEPTION scaling, NHWC or NCHW),
-// sends them in batches (sync or -a async) and prints the top `-c` classes
-// returned by the classification extension.
+// Image classification client (HTTP or gRPC, -i): reads the model's metadata +
+// config to learn its input layout / type, preprocesses images, sends them in
+// batches (sync or -a async) and prints the top `-c` classes returned by the
+// classification extension.
+//
+// Two preprocessing paths (--preprocess):
+//   host  2-tap bilinear resize on the CPU as cv::resize does, NONE / VGG /
+//         INCEPTION scaling, NHWC or NCHW; the tensor travels in the request
+//   hip   the decoded u8 images go to the GPU and ONE fused kernel (resize +
+//         scale + layout + cast, same 2-tap windows in 22-bit fixed point)
+//         writes the batch into a slot of a HIP shared-memory region the
+//         server reads in place; with -a up to --ring-depth requests are in
+//         flight while the next batch is preprocessed.  The kernels come from
+//         libtca_hip.so, loaded at run time (--hip-lib or TCA_HIP_LIB).
+//
+// Images are PNG or binary PPM/PGM files (tca/image_io.h - OpenCV is not part of
+// this toolchain) or `--synthetic N` generated ones; `--decode-only` prints
+// geometry and a pixel hash per file and exits.
 //
 // Behavioural reference: `src/c++/examples/image_client.cc:85-276,537-702,1030-1052`.
-// OpenCV is not available in this toolchain, so images are binary PPM/PGM
-// files (P6/P5) or `--synthetic N` generated ones.  For GPU-side preprocessing
-// see the Python `image_client.py --gpu-preprocess` (HIP kernel + hipshm).
+#include <dlfcn.h>
+
 #include <cmath>
 #include <condition_variable>
-#include <fstream>
+#include <deque>
+#include <map>
 #include <mutex>
 #include <sstream>
 
+#include "../hip/kernels.h"
 #include "example_utils.h"
 #include "tca/codec.h"
+#include "tca/image_io.h"
 
 namespace {
 
@@ -33,32 +48,6 @@ struct ModelInfo {
   bool nhwc = false;
   int max_batch_size = 0;
 };
-
-bool ReadPnm(const std::string& path, Image* img) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) return false;
-  std::string magic;
-  f >> magic;
-  if (magic != "P6" && magic != "P5") return false;
-  auto next_int = [&]() {
-    std::string tok;
-    while (f >> tok) {
-      if (tok[0] == '#') { std::string rest; std::getline(f, rest); continue; }
-      return std::atoi(tok.c_str());
-    }
-    return 0;
-  };
-  img->w = next_int();
-  img->h = next_int();
-  const int maxval = next_int();
-  f.get();
-  if (img->w <= 0 || img->h <= 0 || maxval != 255) return false;
-  img->c = magic == "P6" ? 3 : 1;
-  img->px.resize(static_cast<size_t>(img->w) * img->h * img->c);
-  f.read(reinterpret_cast<char*>(img->px.data()), static_cast<std::streamsize>(img->px.size()));
-  img->name = path;
-  return static_cast<size_t>(f.gcount()) == img->px.size();
-}
 
 Image Synthetic(int index) {
   Image img;
@@ -150,9 +139,11 @@ tca::Error Preprocess(const Image& img, const ModelInfo& m, Scale scale, std::ve
 }
 
 tca::Error ParseModel(const std::string& metadata, const std::string& config, ModelInfo* m) {
-  tca::json::Value md, cfg;
+  tca::json::Value md, cfg_doc;
   TCA_RETURN_IF_ERROR(tca::json::Parse(metadata, &md));
-  TCA_RETURN_IF_ERROR(tca::json::Parse(config, &cfg));
+  TCA_RETURN_IF_ERROR(tca::json::Parse(config, &cfg_doc));
+  // gRPC wraps the configuration in a response message: {"config": {...}}
+  tca::json::Value& cfg = cfg_doc.Find("config") != nullptr ? *cfg_doc.Find("config") : cfg_doc;
   if (md["inputs"].Size() != 1) return tca::Error("expecting 1 input, got " + std::to_string(md["inputs"].Size()));
   if (md["outputs"].Size() != 1) return tca::Error("expecting 1 output, got " + std::to_string(md["outputs"].Size()));
   if (cfg["input"].Size() != 1) return tca::Error("expecting 1 input in the model configuration");
@@ -198,111 +189,452 @@ void PrintResult(tc::InferResult* result, const ModelInfo& m, const std::vector<
   }
 }
 
-}  // namespace
 
-int main(int argc, char** argv) {
-  CommonFlags flags = ParseCommonFlags(argc, argv);
-  std::string model, version;
-  size_t batch = 1, classes = 1;
-  Scale scale = Scale::NONE;
-  bool async = false;
-  int synthetic = 0;
-  std::vector<std::string> files;
-  for (size_t i = 0; i < flags.rest.size(); ++i) {
-    const std::string& a = flags.rest[i];
-    auto value = [&]() -> std::string { return i + 1 < flags.rest.size() ? flags.rest[++i] : ""; };
-    if (a == "-m") model = value();
-    else if (a == "-x") version = value();
-    else if (a == "-b") batch = std::strtoul(value().c_str(), nullptr, 10);
-    else if (a == "-c") classes = std::strtoul(value().c_str(), nullptr, 10);
-    else if (a == "-a") async = true;
-    else if (a == "--synthetic") synthetic = std::atoi(value().c_str());
-    else if (a == "-s") {
-      const std::string s = value();
-      scale = s == "INCEPTION" ? Scale::INCEPTION : s == "VGG" ? Scale::VGG : Scale::NONE;
-    } else files.push_back(a);
+// ---------------------------------------------------------------------------
+// GPU path: libtca_hip.so through dlopen, so the example builds with the host
+// compiler and only needs the library (and a GPU) when --preprocess hip is used
+// ---------------------------------------------------------------------------
+struct HipApi {
+  void* lib = nullptr;
+  int (*set_device)(int) = nullptr;
+  int (*stream_create)(int, void**) = nullptr;
+  int (*stream_sync)(void*) = nullptr;
+  int (*stream_destroy)(void*) = nullptr;
+  int (*host_alloc)(uint64_t, void**) = nullptr;
+  int (*host_free)(void*) = nullptr;
+  int (*dev_alloc)(int, uint64_t, void**) = nullptr;
+  int (*dev_free)(void*) = nullptr;
+  int (*copy_async)(void*, const void*, uint64_t, int, void*) = nullptr;
+  int (*preprocess)(const void*, const void*, const void*, void*, const tca::PreprocParams*, int, int, void*) = nullptr;
+  int (*shm_create)(const char*, uint64_t, int, void**) = nullptr;
+  int (*shm_info)(void*, void**, uint8_t*, int*, uint64_t*, int*) = nullptr;
+  int (*shm_destroy)(void*) = nullptr;
+  const char* (*rt_error)() = nullptr;
+  const char* (*shm_error)() = nullptr;
+
+  template <typename F>
+  void Bind(F* fn, const char* symbol) {
+    *fn = reinterpret_cast<F>(dlsym(lib, symbol));
+    if (*fn == nullptr) FAIL("libtca_hip.so has no symbol " << symbol);
   }
-  if (model.empty()) FAIL("-m <model name> is required");
-  auto client = MakeClient(flags);
+
+  void Load(const std::string& wanted, const char* argv0) {
+    std::vector<std::string> candidates;
+    if (!wanted.empty()) candidates.push_back(wanted);
+    if (const char* env = std::getenv("TCA_HIP_LIB")) candidates.push_back(env);
+    const std::string exe = argv0;
+    const size_t slash = exe.rfind('/');
+    if (slash != std::string::npos) candidates.push_back(exe.substr(0, slash) + "/../../triton_client_amd/_lib/libtca_hip.so");
+    candidates.push_back("libtca_hip.so");
+    std::string errors;
+    for (const auto& path : candidates) {
+      lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (lib != nullptr) break;
+      errors += std::string("\n  ") + dlerror();
+    }
+    if (lib == nullptr) FAIL("unable to load libtca_hip.so (build it with `python -m triton_client_amd._build hip`):" << errors);
+    Bind(&set_device, "tca_hip_set_device");
+    Bind(&stream_create, "tca_hip_stream_create");
+    Bind(&stream_sync, "tca_hip_stream_sync");
+    Bind(&stream_destroy, "tca_hip_stream_destroy");
+    Bind(&host_alloc, "tca_hip_host_alloc");
+    Bind(&host_free, "tca_hip_host_free");
+    Bind(&dev_alloc, "tca_hip_malloc");
+    Bind(&dev_free, "tca_hip_free");
+    Bind(&copy_async, "tca_hip_memcpy_async");
+    Bind(&preprocess, "tca_preprocess_launch");
+    Bind(&shm_create, "tca_hipshm_create");
+    Bind(&shm_info, "tca_hipshm_info");
+    Bind(&shm_destroy, "tca_hipshm_destroy");
+    Bind(&rt_error, "tca_hip_rt_error");
+    Bind(&shm_error, "tca_hip_last_error");
+  }
+};
+
+#define HIP_CALL(API, EXPR, WHAT)                                                   \
+  do {                                                                              \
+    const int rc__ = (EXPR);                                                        \
+    if (rc__ != 0) FAIL(WHAT << " failed (" << rc__ << "): " << (API).rt_error()); \
+  } while (0)
+
+// 2-tap windows with half-pixel centres (the geometry of ResizeToFloat) in the kernel's table form:
+// bounds = (first source index, taps) per output index, coeffs = 22-bit fixed-point weights.
+void LinearTable(int in_size, int out_size, std::vector<int32_t>* bounds, std::vector<int32_t>* coeffs) {
+  const double scale = static_cast<double>(in_size) / out_size;
+  const int32_t one = 1 << 22;
+  for (int o = 0; o < out_size; ++o) {
+    if (in_size == 1) {
+      bounds->insert(bounds->end(), {0, 1});
+      coeffs->insert(coeffs->end(), {one, 0});
+      continue;
+    }
+    double f = (o + 0.5) * scale - 0.5;
+    int s = static_cast<int>(std::floor(f));
+    f -= s;
+    if (s < 0) { s = 0; f = 0.0; }
+    if (s >= in_size - 1) { s = in_size - 2; f = 1.0; }
+    const int32_t w1 = static_cast<int32_t>(f * one + 0.5);
+    bounds->insert(bounds->end(), {s, 2});
+    coeffs->insert(coeffs->end(), {one - w1, w1});
+  }
+}
+
+int DtypeCode(const std::string& dt) {
+  static const std::map<std::string, int> codes = {{"FP32", tca::kF32}, {"FP16", tca::kF16}, {"BF16", tca::kBF16}, {"INT8", tca::kI8},
+                                                   {"UINT8", tca::kU8}, {"INT16", tca::kI16}, {"UINT16", tca::kU16},
+                                                   {"INT32", tca::kI32}, {"UINT32", tca::kU32}, {"FP64", tca::kF64}};
+  const auto it = codes.find(dt);
+  if (it == codes.end()) FAIL("unsupported input datatype " << dt << " for --preprocess hip");
+  return it->second;
+}
+
+size_t DtypeBytes(const std::string& dt) {
+  if (dt == "FP64") return 8;
+  if (dt == "FP32" || dt == "INT32" || dt == "UINT32") return 4;
+  if (dt == "FP16" || dt == "BF16" || dt == "INT16" || dt == "UINT16") return 2;
+  return 1;
+}
+
+// Device-side input stage: staging buffers, coefficient tables of every image geometry in the run,
+// and one HIP shared-memory region cut into `depth` batch slots.
+class HipStage {
+ public:
+  HipStage(const HipApi& api, int device, const ModelInfo& m, Scale scale, size_t batch, size_t depth,
+           const std::vector<Image>& images)
+      : api_(api), device_(device), model_(m), batch_(batch), depth_(depth) {
+    HIP_CALL(api_, api_.set_device(device), "hipSetDevice");
+    HIP_CALL(api_, api_.stream_create(device, &stream_), "hipStreamCreate");
+    // tables: one x/y pair per distinct (height, width)
+    std::vector<int32_t> bounds, coeffs;
+    size_t largest = 0;
+    int tile_h = 16;
+    for (const auto& img : images) {
+      largest = std::max(largest, (img.px.size() + 15) & ~size_t(15));
+      const auto key = std::make_pair(img.h, img.w);
+      if (geometry_.count(key)) continue;
+      Geometry g;
+      g.xb_off = static_cast<int>(bounds.size() / 2);
+      g.xk_off = static_cast<int>(coeffs.size());
+      LinearTable(img.w, m.w, &bounds, &coeffs);
+      g.yb_off = static_cast<int>(bounds.size() / 2);
+      g.yk_off = static_cast<int>(coeffs.size());
+      LinearTable(img.h, m.h, &bounds, &coeffs);
+      geometry_[key] = g;
+    }
+    // tile plan: the tallest tile whose source rows fit the LDS budget for every geometry, then the
+    // widest source span of a 64-column tile (sizes the staged rows)
+    auto rows_of = [&](const Geometry& g, int th) {
+      int worst = 1;
+      for (int oy0 = 0; oy0 < m.h; oy0 += th) {
+        const int last = std::min(oy0 + th, m.h) - 1;
+        worst = std::max(worst, bounds[2 * (g.yb_off + last)] + bounds[2 * (g.yb_off + last) + 1] - bounds[2 * (g.yb_off + oy0)]);
+      }
+      return worst;
+    };
+    int max_rows = 1, span_px = 1;
+    for (;; tile_h /= 2) {
+      max_rows = 1;
+      for (const auto& kv : geometry_) max_rows = std::max(max_rows, rows_of(kv.second, tile_h));
+      if (static_cast<size_t>(max_rows) * (m.c * 64 + 4) <= 48 * 1024) break;
+      if (tile_h == 1) FAIL("down-scaling factor too large for the preprocessing kernel");
+    }
+    for (const auto& kv : geometry_)
+      for (int ox0 = 0; ox0 < m.w; ox0 += 64) {
+        const int last = std::min(ox0 + 64, m.w) - 1;
+        const int xb = kv.second.xb_off;
+        span_px = std::max(span_px, bounds[2 * (xb + last)] + bounds[2 * (xb + last) + 1] - bounds[2 * (xb + ox0)]);
+      }
+    prm_.out_h = m.h;
+    prm_.out_w = m.w;
+    prm_.out_c = m.c;
+    prm_.nhwc = m.nhwc ? 1 : 0;
+    prm_.tile_h = tile_h;
+    prm_.max_rows = max_rows;
+    const int pitch_words = ((span_px * 3 + 3) / 4) | 1;
+    prm_.src_pitch = static_cast<size_t>(max_rows) * (m.c * 64 + 4 + pitch_words * 4) <= 64 * 1024 ? pitch_words * 4 : 0;
+    prm_.pad_ = 0;
+    prm_.image_stride = static_cast<long long>(m.c) * m.h * m.w;
+    for (int c = 0; c < 4; ++c) {
+      prm_.scale[c] = scale == Scale::INCEPTION ? 1.0f / 127.5f : 1.0f;
+      prm_.bias[c] = scale == Scale::INCEPTION ? -1.0f
+                     : scale == Scale::VGG     ? (m.c == 1 ? -128.0f : c == 0 ? -123.0f : c == 1 ? -117.0f : c == 2 ? -104.0f : 0.0f)
+                                               : 0.0f;
+    }
+    dtype_ = DtypeCode(m.input_datatype);
+    slot_bytes_ = batch * static_cast<size_t>(m.c) * m.h * m.w * DtypeBytes(m.input_datatype);
+    stage_bytes_ = largest * batch;
+    HIP_CALL(api_, api_.host_alloc(stage_bytes_, &pinned_), "hipHostMalloc");
+    HIP_CALL(api_, api_.dev_alloc(device, stage_bytes_, &dev_src_), "hipMalloc");
+    HIP_CALL(api_, api_.dev_alloc(device, sizeof(tca::PreprocImage) * batch, &dev_desc_), "hipMalloc");
+    HIP_CALL(api_, api_.dev_alloc(device, bounds.size() * 4, &dev_bounds_), "hipMalloc");
+    HIP_CALL(api_, api_.dev_alloc(device, coeffs.size() * 4, &dev_coeffs_), "hipMalloc");
+    HIP_CALL(api_, api_.copy_async(dev_bounds_, bounds.data(), bounds.size() * 4, 1, stream_), "table upload");
+    HIP_CALL(api_, api_.copy_async(dev_coeffs_, coeffs.data(), coeffs.size() * 4, 1, stream_), "table upload");
+    HIP_CALL(api_, api_.stream_sync(stream_), "hipStreamSynchronize");
+    if (api_.shm_create(kRegion, slot_bytes_ * depth, device, &region_) != 0) FAIL("creating the input region: " << api_.shm_error());
+    int dev = 0, is_host = 0;
+    uint64_t size = 0;
+    if (api_.shm_info(region_, &region_ptr_, raw_handle_, &dev, &size, &is_host) != 0) FAIL("region info: " << api_.shm_error());
+  }
+
+  ~HipStage() {
+    if (region_) api_.shm_destroy(region_);
+    for (void* p : {dev_src_, dev_desc_, dev_bounds_, dev_coeffs_})
+      if (p) api_.dev_free(p);
+    if (pinned_) api_.host_free(pinned_);
+    if (stream_) api_.stream_destroy(stream_);
+  }
+
+  static constexpr const char* kRegion = "image_client_input";
+  const uint8_t* raw_handle() const { return raw_handle_; }
+  size_t region_bytes() const { return slot_bytes_ * depth_; }
+  size_t slot_bytes() const { return slot_bytes_; }
+  size_t depth() const { return depth_; }
+
+  // Preprocesses `batch` into slot `slot` and waits for the kernel: the server reads from another process.
+  void Fill(const std::vector<const Image*>& batch, size_t slot) {
+    std::vector<tca::PreprocImage> desc(batch.size());
+    size_t cursor = 0;
+    for (size_t i = 0; i < batch.size(); ++i) {
+      const Image& img = *batch[i];
+      const Geometry& g = geometry_.at(std::make_pair(img.h, img.w));
+      std::memcpy(static_cast<uint8_t*>(pinned_) + cursor, img.px.data(), img.px.size());
+      tca::PreprocImage& d = desc[i];
+      d.src = static_cast<const uint8_t*>(dev_src_) + cursor;
+      d.height = img.h;
+      d.width = img.w;
+      d.stride = img.w * img.c;
+      d.channels = img.c;
+      d.bgr = 0;
+      d.kx = d.ky = 2;
+      d.xb_off = g.xb_off;
+      d.yb_off = g.yb_off;
+      d.xk_off = g.xk_off;
+      d.yk_off = g.yk_off;
+      d.pad_ = 0;
+      cursor += (img.px.size() + 15) & ~size_t(15);
+    }
+    HIP_CALL(api_, api_.copy_async(dev_src_, pinned_, cursor, 1, stream_), "image upload");
+    HIP_CALL(api_, api_.copy_async(dev_desc_, desc.data(), desc.size() * sizeof(tca::PreprocImage), 1, stream_), "descriptor upload");
+    const int rc = api_.preprocess(dev_desc_, dev_bounds_, dev_coeffs_, static_cast<uint8_t*>(region_ptr_) + slot * slot_bytes_,
+                                   &prm_, static_cast<int>(batch.size()), dtype_, stream_);
+    if (rc != 0) FAIL("tca_preprocess_launch failed (" << rc << ")");
+    HIP_CALL(api_, api_.stream_sync(stream_), "hipStreamSynchronize");
+  }
+
+ private:
+  struct Geometry { int xb_off, yb_off, xk_off, yk_off; };
+  const HipApi& api_;
+  int device_;
+  ModelInfo model_;
+  size_t batch_, depth_;
+  std::map<std::pair<int, int>, Geometry> geometry_;
+  tca::PreprocParams prm_{};
+  int dtype_ = 0;
+  size_t slot_bytes_ = 0, stage_bytes_ = 0;
+  void *stream_ = nullptr, *pinned_ = nullptr, *dev_src_ = nullptr, *dev_desc_ = nullptr, *dev_bounds_ = nullptr, *dev_coeffs_ = nullptr;
+  void *region_ = nullptr, *region_ptr_ = nullptr;
+  uint8_t raw_handle_[64] = {};
+};
+
+struct Options {
+  std::string model, version, hip_lib;
+  size_t batch = 1, classes = 1, ring_depth = 4;
+  Scale scale = Scale::NONE;
+  bool async = false, hip = false, decode_only = false;
+  int synthetic = 0, device = 0;
+  std::vector<std::string> files;
+};
+
+template <typename Client>
+int Run(Client* client, const CommonFlags& flags, const Options& opt, std::vector<Image>& images, const char* argv0) {
   std::string metadata, config;
-  FAIL_IF_ERR(client->ModelMetadata(&metadata, model, version, flags.headers), "failed to get model metadata");
-  FAIL_IF_ERR(client->ModelConfig(&config, model, version, flags.headers), "failed to get model config");
+  FAIL_IF_ERR(client->ModelMetadata(&metadata, opt.model, opt.version, flags.headers), "failed to get model metadata");
+  FAIL_IF_ERR(client->ModelConfig(&config, opt.model, opt.version, flags.headers), "failed to get model config");
   ModelInfo info;
   FAIL_IF_ERR(ParseModel(metadata, config, &info), "model is not an image classifier");
+  const size_t batch = opt.batch, classes = opt.classes;
   if (info.max_batch_size == 0 && batch != 1) FAIL("this model does not support batching");
   if (info.max_batch_size > 0 && static_cast<int>(batch) > info.max_batch_size)
     FAIL("batch size " << batch << " exceeds the model's maximum " << info.max_batch_size);
 
-  std::vector<Image> images;
-  for (const auto& f : files) {
-    Image img;
-    if (!ReadPnm(f, &img)) FAIL("unable to read '" << f << "' (binary PPM/PGM expected)");
-    images.push_back(std::move(img));
+  // the model's channel count decides gray / RGB, as the decode step of the reference does
+  for (auto& img : images) {
+    if (img.c == info.c) continue;
+    tca::DecodedImage in, out;
+    in.height = img.h; in.width = img.w; in.channels = img.c; in.pixels.swap(img.px);
+    tca::ConvertChannels(in, info.c, &out);
+    img.c = info.c;
+    img.px.swap(out.pixels);
   }
-  for (int i = 0; i < synthetic; ++i) images.push_back(Synthetic(i));
-  if (images.empty()) FAIL("no images given (pass .ppm files or --synthetic N)");
-  std::vector<std::vector<uint8_t>> tensors(images.size());
-  for (size_t i = 0; i < images.size(); ++i) FAIL_IF_ERR(Preprocess(images[i], info, scale, &tensors[i]), "preprocessing");
+
+  HipApi api;
+  std::unique_ptr<HipStage> stage;
+  std::vector<std::vector<uint8_t>> tensors;
+  if (opt.hip) {
+    api.Load(opt.hip_lib, argv0);
+    stage.reset(new HipStage(api, opt.device, info, opt.scale, batch, opt.async ? opt.ring_depth : 1, images));
+    FAIL_IF_ERR(client->RegisterCudaSharedMemory(HipStage::kRegion, stage->raw_handle(), opt.device, stage->region_bytes()),
+                "registering the input region");
+  } else {
+    tensors.resize(images.size());
+    for (size_t i = 0; i < images.size(); ++i) FAIL_IF_ERR(Preprocess(images[i], info, opt.scale, &tensors[i]), "preprocessing");
+  }
 
   std::vector<int64_t> shape;
   if (info.max_batch_size > 0) shape.push_back(static_cast<int64_t>(batch));
   if (info.nhwc) { shape.push_back(info.h); shape.push_back(info.w); shape.push_back(info.c); }
   else { shape.push_back(info.c); shape.push_back(info.h); shape.push_back(info.w); }
-  auto input = NewInput(info.input_name, shape, info.input_datatype);
+  // host path: one InferInput reused for every batch (Reset + AppendRaw per image);
+  // hip path: one InferInput per ring slot, pointing at the slot for good
+  const size_t slots = stage ? stage->depth() : 1;
+  std::vector<std::unique_ptr<tc::InferInput>> inputs;
+  for (size_t s = 0; s < slots; ++s) {
+    inputs.push_back(NewInput(info.input_name, shape, info.input_datatype));
+    if (stage) FAIL_IF_ERR(inputs[s]->SetSharedMemory(HipStage::kRegion, stage->slot_bytes(), s * stage->slot_bytes()), "input region");
+  }
   auto output = NewOutput(info.output_name, classes);
-  tc::InferOptions options(model);
-  options.model_version_ = version;
+  tc::InferOptions options(opt.model);
+  options.model_version_ = opt.version;
   options.client_timeout_ = flags.client_timeout_us;
 
   std::mutex mu;
   std::condition_variable cv;
   size_t pending = 0;
-  std::vector<std::pair<std::unique_ptr<tc::InferResult>, std::vector<std::string>>> async_results;
-  // one InferInput is reused for every batch: Reset() + AppendRaw per image; the
-  // last batch wraps around to the first images to stay full
-  size_t idx = 0;
+  std::deque<size_t> free_slots;
+  for (size_t s = 0; s < slots; ++s) free_slots.push_back(s);
+  std::map<size_t, std::pair<std::unique_ptr<tc::InferResult>, std::vector<std::string>>> async_results;
+  // the last batch wraps around to the first images to stay full
+  size_t idx = 0, sent = 0;
   bool last = false;
   while (!last) {
-    FAIL_IF_ERR(input->Reset(), "resetting input");
+    size_t slot = 0;
+    if (stage) {  // a slot is refilled only after the response of the request that read it
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !free_slots.empty(); });
+      slot = free_slots.front();
+      free_slots.pop_front();
+    }
+    tc::InferInput* input = inputs[slot].get();
+    if (!stage) FAIL_IF_ERR(input->Reset(), "resetting input");
     std::vector<std::string> names;
+    std::vector<const Image*> members;
     for (size_t b = 0; b < batch; ++b) {
-      FAIL_IF_ERR(input->AppendRaw(tensors[idx]), "appending image");
+      if (stage) members.push_back(&images[idx]);
+      else FAIL_IF_ERR(input->AppendRaw(tensors[idx]), "appending image");
       names.push_back(images[idx].name);
       idx = (idx + 1) % images.size();
       if (idx == 0) last = true;
     }
-    options.request_id_ = std::to_string(idx);
-    if (async) {
+    if (stage) stage->Fill(members, slot);
+    const size_t seq = ++sent;
+    options.request_id_ = std::to_string(seq);
+    if (opt.async) {
       {
         std::lock_guard<std::mutex> lk(mu);
         ++pending;
       }
-      // the request references `tensors`, which outlive the call
+      // the request references `tensors` / the region, which outlive the call
       FAIL_IF_ERR(client->AsyncInfer(
-                      [&, names](tc::InferResult* r) {
+                      [&, names, seq, slot](tc::InferResult* r) {
                         std::lock_guard<std::mutex> lk(mu);
-                        async_results.emplace_back(std::unique_ptr<tc::InferResult>(r), names);
+                        async_results[seq] = std::make_pair(std::unique_ptr<tc::InferResult>(r), names);
                         --pending;
-                        cv.notify_one();
+                        if (stage) free_slots.push_back(slot);
+                        cv.notify_all();
                       },
-                      options, {input.get()}, {output.get()}, flags.headers),
+                      options, {input}, {output.get()}, flags.headers),
                   "failed to send asynchronous infer request");
-      // the shared InferInput is rewritten for the next batch: wait for this one to be on the wire
-      std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return pending == 0; });
+      if (!stage) {  // the shared InferInput is rewritten for the next batch: wait for this one
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return pending == 0; });
+      }
     } else {
       tc::InferResult* result = nullptr;
-      FAIL_IF_ERR(client->Infer(&result, options, {input.get()}, {output.get()}, flags.headers),
+      FAIL_IF_ERR(client->Infer(&result, options, {input}, {output.get()}, flags.headers),
                   "failed to send synchronous infer request");
       std::unique_ptr<tc::InferResult> guard(result);
       std::cout << "Request " << options.request_id_ << ", batch size " << batch << std::endl;
       PrintResult(result, info, names, classes);
+      if (stage) {
+        std::lock_guard<std::mutex> lk(mu);
+        free_slots.push_back(slot);
+      }
     }
   }
-  for (auto& r : async_results) {
-    FAIL_IF_ERR(r.first->RequestStatus(), "asynchronous inference failed");
-    PrintResult(r.first.get(), info, r.second, classes);
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return pending == 0; });
   }
+  for (auto& r : async_results) {
+    FAIL_IF_ERR(r.second.first->RequestStatus(), "asynchronous inference failed");
+    std::cout << "Request " << r.first << ", batch size " << batch << std::endl;
+    PrintResult(r.second.first.get(), info, r.second.second, classes);
+  }
+  if (stage) FAIL_IF_ERR(client->UnregisterCudaSharedMemory(HipStage::kRegion), "unregistering the input region");
   std::cout << "PASS : Image Client" << std::endl;
   return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  CommonFlags flags = ParseCommonFlags(argc, argv);
+  Options opt;
+  std::string protocol = "http";
+  for (size_t i = 0; i < flags.rest.size(); ++i) {
+    const std::string& a = flags.rest[i];
+    auto value = [&]() -> std::string { return i + 1 < flags.rest.size() ? flags.rest[++i] : ""; };
+    if (a == "-m") opt.model = value();
+    else if (a == "-x") opt.version = value();
+    else if (a == "-i") protocol = value();
+    else if (a == "-b") opt.batch = std::strtoul(value().c_str(), nullptr, 10);
+    else if (a == "-c") opt.classes = std::strtoul(value().c_str(), nullptr, 10);
+    else if (a == "-a") opt.async = true;
+    else if (a == "-g") opt.device = std::atoi(value().c_str());
+    else if (a == "--synthetic") opt.synthetic = std::atoi(value().c_str());
+    else if (a == "--decode-only") opt.decode_only = true;
+    else if (a == "--hip-lib") opt.hip_lib = value();
+    else if (a == "--ring-depth") opt.ring_depth = std::max<size_t>(1, std::strtoul(value().c_str(), nullptr, 10));
+    else if (a == "--preprocess") {
+      const std::string p = value();
+      if (p != "host" && p != "hip") FAIL("--preprocess takes host or hip");
+      opt.hip = p == "hip";
+    } else if (a == "-s") {
+      const std::string s = value();
+      opt.scale = s == "INCEPTION" ? Scale::INCEPTION : s == "VGG" ? Scale::VGG : Scale::NONE;
+    } else opt.files.push_back(a);
+  }
+  for (auto& ch : protocol) ch = static_cast<char>(std::tolower(ch));
+  if (protocol != "http" && protocol != "grpc") FAIL("-i takes http or grpc");
+
+  std::vector<Image> images;
+  for (const auto& f : opt.files) {
+    tca::DecodedImage decoded;
+    FAIL_IF_ERR(tca::ReadImageFile(f, &decoded), "unable to read '" + f + "'");
+    Image img;
+    img.h = decoded.height;
+    img.w = decoded.width;
+    img.c = decoded.channels;
+    img.px.swap(decoded.pixels);
+    img.name = f;
+    images.push_back(std::move(img));
+  }
+  if (opt.decode_only) {
+    for (const auto& img : images) {
+      uint64_t hash = 1469598103934665603ull;  // FNV-1a over the pixels
+      for (uint8_t p : img.px) hash = (hash ^ p) * 1099511628211ull;
+      std::cout << img.name << " " << img.h << " " << img.w << " " << img.c << " " << hash << std::endl;
+    }
+    return 0;
+  }
+  for (int i = 0; i < opt.synthetic; ++i) images.push_back(Synthetic(i));
+  if (images.empty()) FAIL("no images given (pass .png / .ppm files or --synthetic N)");
+  if (opt.model.empty()) FAIL("-m <model name> is required");
+  if (protocol == "grpc") {
+    auto client = MakeGrpcClient(flags);
+    return Run(client.get(), flags, opt, images, argv[0]);
+  }
+  auto client = MakeClient(flags);
+  return Run(client.get(), flags, opt, images, argv[0]);
 }

@@ -131,3 +131,111 @@ def test_cpp_examples(built, server, name):
         args += ["-c", "2", "--synthetic", "2"]
     out = _run(args)
     assert "PASS" in out
+
+
+def _fnv1a(data):
+    h = 1469598103934665603
+    for b in bytes(data):
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _write_adam7_png(path, pixels):
+    """An interlaced 8-bit RGB PNG written by hand (Pillow does not write Adam7)."""
+    import struct
+    import zlib
+
+    h, w, _ = pixels.shape
+    raw = b""
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = pixels[y0::dy, x0::dx]
+        if sub.size == 0:
+            continue
+        for row in sub:
+            raw += b"\x00" + row.tobytes()
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) +
+                 chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def test_cpp_png_reader_matches_pillow(built, tmp_path):
+    """The zlib-based PNG reader of the C++ library against Pillow, over colour types, bit depths,
+    filters (Pillow picks them adaptively for photographic content) and Adam7."""
+    import numpy as np
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:37, 0:53]
+    smooth = np.stack([(xx * 4 + yy) % 256, (yy * 6 + xx // 2) % 256, (xx + yy) * 2 % 256], axis=-1).astype(np.uint8)
+    noisy = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    expected = {}
+
+    def save(name, img, want):
+        path = str(tmp_path / name)
+        img.save(path)
+        expected[path] = want
+
+    for label, arr in (("smooth", smooth), ("noisy", noisy)):
+        save(f"rgb_{label}.png", Image.fromarray(arr), arr)
+        save(f"gray_{label}.png", Image.fromarray(arr[..., 0]), arr[..., 0])
+        rgba = np.concatenate([arr, rng.integers(0, 256, size=(37, 53, 1), dtype=np.uint8)], axis=-1)
+        save(f"rgba_{label}.png", Image.fromarray(rgba), arr)
+        la = np.stack([arr[..., 1], rgba[..., 3]], axis=-1)
+        save(f"la_{label}.png", Image.fromarray(la, "LA"), arr[..., 1])
+    pal = Image.fromarray(smooth).quantize(colors=16)
+    save("palette4.png", pal, np.asarray(pal.convert("RGB")))
+    pal256 = Image.fromarray(noisy).quantize(colors=200)
+    save("palette8.png", pal256, np.asarray(pal256.convert("RGB")))
+    bilevel = Image.fromarray((smooth[..., 0] > 127).astype(np.uint8) * 255).convert("1")
+    save("bilevel.png", bilevel, np.asarray(bilevel.convert("L")))
+    deep = (rng.integers(0, 65536, size=(19, 23), dtype=np.uint16))
+    save("gray16.png", Image.fromarray(deep), (deep >> 8).astype(np.uint8))
+    inter = str(tmp_path / "adam7.png")
+    _write_adam7_png(inter, noisy)
+    expected[inter] = noisy
+    ppm = str(tmp_path / "plain.ppm")
+    with open(ppm, "wb") as fh:
+        fh.write(b"P6\n# comment\n53 37\n255\n" + smooth.tobytes())
+    expected[ppm] = smooth
+
+    out = _run([os.path.join(built, "image_client"), "--decode-only", *expected])
+    rows = {line.split()[0]: line.split()[1:] for line in out.strip().splitlines()}
+    assert set(rows) == set(expected)
+    for path, want in expected.items():
+        h, w = want.shape[:2]
+        c = 1 if want.ndim == 2 else 3
+        assert rows[path] == [str(h), str(w), str(c), str(_fnv1a(want.tobytes()))], path
+
+    # a flipped byte must be caught by the chunk checksum, not decoded
+    bad = str(tmp_path / "bad.png")
+    data = bytearray(open(str(tmp_path / "rgb_noisy.png"), "rb").read())
+    data[len(data) // 2] ^= 0x40
+    open(bad, "wb").write(bytes(data))
+    p = subprocess.run([os.path.join(built, "image_client"), "--decode-only", bad], capture_output=True, text=True)
+    assert p.returncode != 0 and "PNG" in (p.stdout + p.stderr)
+
+
+@pytest.mark.parametrize("protocol,mode", [("http", ()), ("grpc", ()), ("grpc", ("-a",))])
+def test_cpp_image_client_png_files(built, server, tmp_path, protocol, mode):
+    """PNG input over both protocols: same classes whatever the protocol / mode."""
+    import numpy as np
+    from PIL import Image
+
+    rng = np.random.default_rng(11)
+    files = []
+    for i in range(3):
+        path = str(tmp_path / f"img{i}.png")
+        Image.fromarray(rng.integers(0, 256, size=(60 + 8 * i, 80, 3), dtype=np.uint8)).save(path)
+        files.append(path)
+    url = server.http_url if protocol == "http" else server.grpc_url
+    out = _run([os.path.join(built, "image_client"), "-u", url, "-i", protocol, "-m", "tiny_classifier", "-b", "2", "-c", "2",
+                "-s", "INCEPTION", *mode, *files])
+    assert "PASS" in out and out.count("Image '") == 4
+    ref = _run([os.path.join(built, "image_client"), "-u", server.http_url, "-m", "tiny_classifier", "-b", "2", "-c", "2",
+                "-s", "INCEPTION", *files])
+    pick = lambda text: [line for line in text.splitlines() if line.startswith("    ")]  # noqa: E731
+    assert pick(out) == pick(ref)

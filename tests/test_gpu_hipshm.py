@@ -1,6 +1,8 @@
 """hipshm on a real MI355X (intent of the reference's
 ``src/python/library/tests/test_cuda_shared_memory.py:37-164``) plus the
 cross-process IPC path through the in-repo server."""
+import os
+
 import numpy as np
 import pytest
 
@@ -340,3 +342,25 @@ def test_image_pipeline_matches_one_request_at_a_time(hipshm, gpu_server):
         assert len(seen) == len({tuple(e) for e in expected})
     finally:
         pipe.close()
+
+
+@pytest.mark.parametrize("mode", [(), ("-a", "--ring-depth", "2")])
+def test_cpp_image_client_hip_preprocess(gpu_server, mode):
+    """C++ image client with the fused kernel writing into a HIP shared-memory ring: same classes
+    as its CPU preprocessing (float 2-tap bilinear vs the kernel's 22-bit fixed point)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "triton_client_amd", "_lib", "tca_image_client")
+    assert os.path.exists(exe), "run `python -m triton_client_amd._build cpp`"
+    common = [exe, "-u", gpu_server.grpc_url, "-i", "grpc", "-m", "resnet50", "-b", "2", "-c", "3", "-s", "INCEPTION",
+              "--synthetic", "5"]
+
+    def classes(args):
+        p = subprocess.run(args, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0 and "PASS" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+        return [line.split("(")[1].split(")")[0] for line in p.stdout.splitlines() if line.startswith("    ")]
+
+    host = classes(common)
+    dev = classes(common + ["--preprocess", "hip", *mode])
+    assert len(host) == 18 and dev == host

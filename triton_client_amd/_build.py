@@ -114,16 +114,18 @@ def build_cpp(force=False):
         return None
     BUILD.mkdir(exist_ok=True)
     _run(["make", "-C", CSRC, "-j8", f"BUILD={BUILD}"] + (["-B"] if force else []))
-    # the load generator is needed at run time (bench.py, perf --native): keep a copy
-    # next to the shared objects, which is the directory that travels with the package
-    loadgen = BUILD / "bin" / "tca_loadgen"
-    if loadgen.exists():
+    # programs needed at run time (bench.py, perf --native, GPU tests of the C++ image client): keep
+    # copies next to the shared objects, which is the directory that travels with the package
+    for built, installed in (("tca_loadgen", "tca_loadgen"), ("image_client", "tca_image_client")):
+        src = BUILD / "bin" / built
+        if not src.exists():
+            continue
         LIBDIR.mkdir(exist_ok=True)
-        tmp = LIBDIR / f"tca_loadgen.tmp{os.getpid()}"
-        shutil.copy2(loadgen, tmp)
+        tmp = LIBDIR / f"{installed}.tmp{os.getpid()}"
+        shutil.copy2(src, tmp)
         if shutil.which("strip"):
             subprocess.call(["strip", str(tmp)])
-        os.replace(tmp, LIBDIR / "tca_loadgen")
+        os.replace(tmp, LIBDIR / installed)
     return BUILD
 
 
