@@ -127,6 +127,18 @@ bool SplitRawContents(const std::string& msg, std::string* head, std::vector<std
   return true;
 }
 
+}  // namespace
+
+// A Blob owning `data` (new reference), or nullptr with a Python error set.  Shared with the HTTP front.
+PyObject* tca_new_blob(std::string&& data) {
+  auto* blob = PyObject_New(PyBlob, &kBlobType);
+  if (blob == nullptr) return nullptr;
+  blob->data = new std::string(std::move(data));
+  return reinterpret_cast<PyObject*>(blob);
+}
+
+namespace {
+
 void CallPython(PyObject* fn, const char* fmt, ...) {
   if (fn == nullptr || fn == Py_None) return;
   PyGILState_STATE gil = PyGILState_Ensure();

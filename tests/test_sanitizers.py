@@ -1,7 +1,8 @@
 """Race / memory-error detection for the native code: the client library, its
-unit tests, a multi-threaded client stress test and the native gRPC serving front
-(``grpc_front_stress``: epoll reactors answered from completer threads, the serving
-benchmark's hot path, driven in-process by client threads) are rebuilt with
+unit tests, a multi-threaded client stress test and the native serving fronts
+(``grpc_front_stress`` / ``http_front_stress``: epoll reactors answered from completer
+threads, the serving benchmark's hot path, driven in-process by client threads and raw
+sockets) are rebuilt with
 ``-fsanitize=thread`` and with ``-fsanitize=address,undefined`` and run against
 the in-repo server.  (GPU code cannot run under sanitizers on this pool; these
 are host-only builds.)  The reference configures no sanitizers at all."""
@@ -12,7 +13,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TARGETS = ("stress_test", "cc_unit_test", "grpc_client_test", "grpc_front_stress")
+TARGETS = ("stress_test", "cc_unit_test", "grpc_client_test", "grpc_front_stress", "http_front_stress")
 
 
 def _build(kind, san):
@@ -45,3 +46,5 @@ def test_native_clients_under_sanitizer(server, kind, san, env):
     assert "PASS : stress" in r.stdout
     r = run([os.path.join(bins, "grpc_front_stress"), "-n", "6", "-r", "6"])
     assert "PASS : front stress" in r.stdout
+    r = run([os.path.join(bins, "http_front_stress"), "-n", "6", "-r", "6"])
+    assert "PASS : http front stress" in r.stdout

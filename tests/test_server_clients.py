@@ -605,3 +605,121 @@ def test_large_wire_tensors_take_the_zero_copy_path():
             bad._raw_content = b"\0" * 200_000
             with pytest.raises(InferenceServerException, match="byte size"):
                 c.infer("custom_identity_int32", [bad])
+
+
+@pytest.mark.parametrize("impl", ["native", "asyncio"])
+def test_both_http_fronts_serve_the_same_surface(impl):
+    """The native HTTP/1.1 front and the asyncio one are interchangeable behind
+    ``Server(http_impl=...)``: control endpoints, JSON and binary inference, compression in
+    both directions, errors, asynchronous requests, large tensors."""
+    import tritonclient.http as httpclient
+    from triton_client_amd.server import Server
+    from tritonclient.utils import InferenceServerException
+
+    with Server(models=["simple", "simple_string", "custom_identity_int32"], enable_grpc=False, http_impl=impl,
+                model_control="explicit") as srv:
+        with httpclient.InferenceServerClient(srv.http_url, concurrency=4) as c:
+            assert c.is_server_live() and c.is_server_ready()
+            c.load_model("simple")
+            c.load_model("custom_identity_int32")
+            assert c.is_model_ready("simple") and not c.is_model_ready("simple_string")
+            assert c.get_model_config("simple")["name"] == "simple"
+            assert c.get_model_metadata("simple")["inputs"][0]["name"] == "INPUT0"
+            assert {m["name"] for m in c.get_model_repository_index()} >= {"simple", "simple_string"}
+            a = np.arange(16, dtype=np.int32).reshape(1, 16)
+            b = np.full((1, 16), 3, dtype=np.int32)
+            for binary in (True, False):
+                inputs = [httpclient.InferInput("INPUT0", [1, 16], "INT32").set_data_from_numpy(a, binary_data=binary),
+                          httpclient.InferInput("INPUT1", [1, 16], "INT32").set_data_from_numpy(b, binary_data=binary)]
+                outputs = [httpclient.InferRequestedOutput("OUTPUT0", binary_data=binary),
+                           httpclient.InferRequestedOutput("OUTPUT1", binary_data=not binary)]
+                r = c.infer("simple", inputs, outputs=outputs, request_id="7")
+                np.testing.assert_array_equal(r.as_numpy("OUTPUT0"), a + b)
+                np.testing.assert_array_equal(r.as_numpy("OUTPUT1"), a - b)
+                assert r.get_response()["id"] == "7"
+            for algo in ("gzip", "deflate"):
+                r = c.infer("simple", inputs, request_compression_algorithm=algo, response_compression_algorithm=algo)
+                np.testing.assert_array_equal(r.as_numpy("OUTPUT0"), a + b)
+            with pytest.raises(InferenceServerException, match="unknown model"):
+                c.infer("nope", inputs)
+            handles = [c.async_infer("simple", inputs) for _ in range(16)]
+            for h in handles:
+                np.testing.assert_array_equal(h.get_result().as_numpy("OUTPUT1"), a - b)
+            x = np.arange(300_000, dtype=np.int32).reshape(1, -1)  # 1.2 MB: above the zero-copy threshold
+            inp = httpclient.InferInput("INPUT0", list(x.shape), "INT32").set_data_from_numpy(x)
+            np.testing.assert_array_equal(c.infer("custom_identity_int32", [inp]).as_numpy("OUTPUT0"), x)
+            stats = c.get_inference_statistics("simple")["model_stats"][0]
+            assert stats["inference_count"] >= 20
+            c.unload_model("simple")
+            assert not c.is_model_ready("simple")
+
+
+def _raw_http(port, payload, expect_close=False, timeout=5.0):
+    """Sends raw bytes, returns everything received until the peer is idle / closes."""
+    import socket
+
+    s = socket.create_connection(("127.0.0.1", port), timeout=timeout)
+    try:
+        s.sendall(payload)
+        s.settimeout(0.5 if not expect_close else timeout)
+        data = b""
+        while True:
+            try:
+                chunk = s.recv(65536)
+            except socket.timeout:
+                break
+            if not chunk:
+                break
+            data += chunk
+        return data
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("impl", ["native", "asyncio"])
+def test_http_front_protocol_edges(impl):
+    """Wire-level behaviour a well-behaved HTTP/1.1 server owes its clients."""
+    import json
+
+    from triton_client_amd.server import Server
+
+    body = json.dumps({"inputs": [
+        {"name": "INPUT0", "datatype": "INT32", "shape": [1, 16], "data": list(range(16))},
+        {"name": "INPUT1", "datatype": "INT32", "shape": [1, 16], "data": [1] * 16}]}).encode()
+    with Server(models=["simple"], enable_grpc=False, http_impl=impl) as srv:
+        port = int(srv.http_url.rsplit(":", 1)[1])
+        post = b"POST /v2/models/simple/infer HTTP/1.1\r\nHost: x\r\nContent-Length: %d\r\n\r\n" % len(body) + body
+        # two requests back to back on one connection: two answers, in order
+        out = _raw_http(port, post + b"GET /v2/health/live HTTP/1.1\r\nHost: x\r\n\r\n")
+        assert out.count(b"HTTP/1.1 200 OK") == 2 and b'"OUTPUT0"' in out
+        # Expect: 100-continue with the body held back
+        import socket
+
+        s = socket.create_connection(("127.0.0.1", port), timeout=5)
+        s.sendall(b"POST /v2/models/simple/infer HTTP/1.1\r\nHost: x\r\nExpect: 100-continue\r\nContent-Length: %d\r\n\r\n"
+                  % len(body))
+        assert s.recv(1024).startswith(b"HTTP/1.1 100 Continue")
+        s.sendall(body)
+        assert b"200 OK" in s.recv(65536)
+        s.close()
+        # Connection: close is honoured
+        out = _raw_http(port, b"GET /v2/health/ready HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n", expect_close=True)
+        assert b"200 OK" in out and b"connection: close" in out.lower()
+        # unknown endpoint and malformed JSON are 4xx with a JSON error, the connection survives
+        out = _raw_http(port, b"GET /v2/nothing HTTP/1.1\r\nHost: x\r\n\r\nGET /v2/health/live HTTP/1.1\r\nHost: x\r\n\r\n")
+        assert b"404" in out.split(b"\r\n", 1)[0] and out.count(b"HTTP/1.1 200 OK") == 1
+        bad = b"{not json"
+        out = _raw_http(port, b"POST /v2/models/simple/infer HTTP/1.1\r\nHost: x\r\nContent-Length: %d\r\n\r\n" % len(bad) + bad)
+        assert b"400" in out.split(b"\r\n", 1)[0] and b'"error"' in out
+        if impl == "native":
+            # chunked request body (the asyncio front does not take those)
+            half = len(body) // 2
+            chunked = (b"POST /v2/models/simple/infer HTTP/1.1\r\nHost: x\r\nTransfer-Encoding: chunked\r\n\r\n" +
+                       b"%x\r\n" % half + body[:half] + b"\r\n" + b"%x\r\n" % (len(body) - half) + body[half:] +
+                       b"\r\n0\r\n\r\n")
+            out = _raw_http(port, chunked)
+            assert b"200 OK" in out and b'"OUTPUT1"' in out
+            # garbage instead of a request line: 400 and the connection is closed
+            out = _raw_http(port, b"NONSENSE\r\n\r\n", expect_close=True)
+            assert out.startswith(b"HTTP/1.1 400")
+            assert srv.http.stats()["requests"] >= 6

@@ -29,7 +29,8 @@ class Server:
 
     def __init__(self, models=None, gpu=None, http_port=0, grpc_port=0, host="127.0.0.1", model_control="none",
                  enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32, grpc_impl=None,
-                 tls_cert=None, tls_key=None, tls_client_ca=None, grpc_reactors=None):
+                 tls_cert=None, tls_key=None, tls_client_ca=None, grpc_reactors=None, http_impl=None,
+                 http_reactors=None):
         self.core = InferenceCore(models=models, gpu=gpu, model_control=model_control)
         self.host = host
         self._http_port = http_port
@@ -41,6 +42,10 @@ class Server:
         # "native": C++ HTTP/2 reactors + asynchronous completion; "grpcio": the stock
         # Python gRPC server.  Default from TCA_GRPC_IMPL, else native.
         self._grpc_impl = (grpc_impl or os.environ.get("TCA_GRPC_IMPL") or "native").lower()
+        # "native": C++ HTTP/1.1 reactors + asynchronous completion; "asyncio": the pure-Python
+        # front.  Default from TCA_HTTP_IMPL, else native.
+        self._http_impl = (http_impl or os.environ.get("TCA_HTTP_IMPL") or "native").lower()
+        self._http_reactors = int(http_reactors or os.environ.get("TCA_HTTP_REACTORS") or 2)
         # TLS on both fronts when a certificate + key (PEM files) are given; `tls_client_ca`
         # additionally requires client certificates signed by that CA (mutual TLS)
         self._tls = (tls_cert, tls_key, tls_client_ca) if tls_cert and tls_key else None
@@ -73,7 +78,15 @@ class Server:
             else:
                 raise ValueError(f"unknown gRPC implementation '{self._grpc_impl}' (native | grpcio)")
             self._grpc_port = self.grpc.start()
-        if self._enable_http:
+        if self._enable_http and self._http_impl == "native":
+            from .native_http_front import NativeHttpFront
+
+            self.http = NativeHttpFront(self.core, self.host, self._http_port, workers=self._http_workers,
+                                        reactors=self._http_reactors, tls=self._tls)
+            self._http_port = self.http.start()
+        elif self._enable_http:
+            if self._http_impl != "asyncio":
+                raise ValueError(f"unknown HTTP implementation '{self._http_impl}' (native | asyncio)")
             from .http_front import HttpFront
 
             ready = threading.Event()
@@ -111,6 +124,9 @@ class Server:
             self._loop.call_soon_threadsafe(self._loop.stop)
             self._thread.join(timeout=5)
             self._loop = None
+        elif self.http is not None:
+            self.http.stop()
+        self.http = None
         self.core.shutdown()
 
     def __enter__(self):

@@ -24,6 +24,9 @@ def main(argv=None):
     ap.add_argument("--grpc-workers", type=int, default=32)
     ap.add_argument("--grpc-impl", choices=["native", "grpcio"], default=None,
                     help="gRPC front: native C++ HTTP/2 reactors (default) or the stock Python gRPC server")
+    ap.add_argument("--http-impl", choices=["native", "asyncio"], default=None,
+                    help="HTTP front: C++ reactors (default) or the pure-Python asyncio one")
+    ap.add_argument("--http-reactors", type=int, default=None, help="epoll threads of the native HTTP front (default 2)")
     ap.add_argument("--grpc-reactors", type=int, default=None, help="epoll threads of the native gRPC front (default 2)")
     ap.add_argument("--tls-cert", default=None, help="PEM certificate chain: serve HTTPS / gRPC over TLS")
     ap.add_argument("--tls-key", default=None, help="PEM private key of --tls-cert")
@@ -42,7 +45,8 @@ def main(argv=None):
             models += [n for n, c in MODEL_ZOO.items() if c.device == "gpu" and getattr(c, "autoload", True)]
     server = Server(models=models, gpu=args.gpu, http_port=args.http_port, grpc_port=args.grpc_port, host=args.host,
                     model_control=args.model_control_mode, http_workers=args.http_workers,
-                    grpc_workers=args.grpc_workers, grpc_impl=args.grpc_impl, grpc_reactors=args.grpc_reactors, tls_cert=args.tls_cert,
+                    grpc_workers=args.grpc_workers, grpc_impl=args.grpc_impl, grpc_reactors=args.grpc_reactors, http_impl=args.http_impl,
+                    http_reactors=args.http_reactors, tls_cert=args.tls_cert,
                     tls_key=args.tls_key, tls_client_ca=args.tls_client_ca).start()
     if args.announce:
         print(json.dumps({"http_port": server._http_port, "grpc_port": server._grpc_port,

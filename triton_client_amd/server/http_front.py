@@ -19,7 +19,7 @@ import json
 import re
 import zlib
 from concurrent.futures import ThreadPoolExecutor
-from urllib.parse import parse_qs, unquote, urlsplit
+from urllib.parse import unquote
 
 import numpy as np
 
@@ -151,6 +151,142 @@ def render_infer_response(resp, default_binary):
     return [head], None
 
 
+class Router:
+    """The REST surface without the transport: maps one request to its answer.
+
+    ``route`` returns ``(status, headers, parts)`` for endpoints answered on the spot,
+    ``("blocking", fn)`` for the ones that may take long (model load / unload; ``fn()``
+    gives the answer) and ``("infer", model, version, body)`` for an inference, which the
+    front runs its own way (thread pool, batcher callback, inline)."""
+
+    def __init__(self, core):
+        self.core = core
+
+    def route(self, method, target, headers, body):
+        path, _, _query = target.partition("?")
+        path = (unquote(path) if "%" in path else path).strip("/")
+        core = self.core
+        encoding = headers.get("content-encoding")
+        if encoding == "gzip":
+            body = gzip.decompress(body)
+        elif encoding == "deflate":
+            body = zlib.decompress(body)
+
+        def ok(obj=None):
+            return 200, {}, [_dumps(obj) if obj is not None else b""]
+
+        m = _MODEL_RE.match(path) if path != "v2/models/stats" else None
+        if m:
+            model, version, action = m["model"], m["version"] or "", m["action"]
+            if action == "infer":
+                if method != "POST":
+                    raise ServerError("infer requires POST", 405)
+                return "infer", model, version, body
+            if action is None:
+                return ok(core.model_metadata(model, version))
+            if action == "ready":
+                return (200 if core.is_model_ready(model, version) else 400), {}, [b""]
+            if action == "config":
+                return ok(core.model_config(model, version))
+            if action == "stats":
+                return ok(core.statistics(model, version))
+            if action == "trace/setting":
+                if method == "POST":
+                    return ok(core.update_trace(model, json.loads(bytes(body)) if bytes(body).strip() else {}))
+                return ok(core.get_trace(model))
+            raise ServerError(f"no handler for {method} /{path}", 404)
+        body = bytes(body)
+        if path == "v2/health/live":
+            return (200 if core.live else 400), {}, [b""]
+        if path == "v2/health/ready":
+            return (200 if core.ready else 400), {}, [b""]
+        if path == "v2":
+            return ok(core.server_metadata())
+        if path == "v2/models/stats":
+            return ok(core.statistics())
+        if path == "v2/repository/index":
+            ready = bool(json.loads(body).get("ready", False)) if body.strip() else False
+            return ok(core.repository_index(ready))
+        if path == "v2/trace/setting":
+            if method == "POST":
+                return ok(core.update_trace(None, json.loads(body) if body.strip() else {}))
+            return ok(core.get_trace(None))
+        if path == "v2/logging":
+            if method == "POST":
+                return ok(core.update_log(json.loads(body) if body.strip() else {}))
+            return ok(dict(core.log_settings))
+        m = _REPO_RE.match(path)
+        if m:
+            doc = json.loads(body) if body.strip() else {}
+            params = doc.get("parameters") or {}
+            if m["action"] == "load":
+                files = {k: v for k, v in params.items() if k.startswith("file:")}
+
+                def run(name=m["model"]):
+                    core.load_model(name, params.get("config"), files or None)
+                    return ok()
+            else:
+                def run(name=m["model"]):
+                    core.unload_model(name, bool(params.get("unload_dependents", False)))
+                    return ok()
+            return "blocking", run
+        m = _SHM_RE.match(path)
+        if m:
+            return self._shm(m["kind"], m["region"], m["action"], body, ok)
+        raise ServerError(f"no handler for {method} /{path}", 404)
+
+    def _shm(self, kind, region, action, body, ok):
+        core = self.core
+        reg = core.sysshm if kind == "systemsharedmemory" else core.devshm
+        if action == "status":
+            return ok(reg.status(region or ""))
+        if action == "unregister":
+            reg.unregister(region or "")
+            return ok()
+        if not region:
+            raise ServerError("register requires a region name", 400)
+        doc = json.loads(body) if body.strip() else {}
+        try:
+            if kind == "systemsharedmemory":
+                reg.register(region, doc["key"], int(doc.get("offset", 0)), int(doc["byte_size"]))
+            else:
+                import base64
+
+                raw = base64.b64decode(doc["raw_handle"]["b64"])
+                reg.register(region, raw, int(doc["device_id"]), int(doc["byte_size"]))
+        except KeyError as e:
+            raise ServerError(f"missing field {e} in shared memory register request", 400) from None
+        return ok()
+
+    def parse_infer(self, model, version, headers, body):
+        hl = headers.get("inference-header-content-length")
+        try:
+            header_length = int(hl) if hl is not None else None
+        except ValueError:
+            raise ServerError("malformed Inference-Header-Content-Length", 400) from None
+        return parse_infer_body(model, version, body, header_length)
+
+    @staticmethod
+    def render_infer(resp, req, headers):
+        """Response of an inference -> ``(200, headers, parts)`` (binary extension, compression)."""
+        if not hasattr(resp, "outputs"):
+            raise ServerError(
+                f"model '{req.model_name}' is decoupled and can only be used through the gRPC streaming API", 400)
+        parts, json_len = render_infer_response(resp, getattr(req, "http_default_binary", False))
+        rh = {}
+        if json_len is not None:
+            rh["Inference-Header-Content-Length"] = str(json_len)
+            rh["Content-Type"] = "application/octet-stream"
+        accept = headers.get("accept-encoding", "")
+        if "gzip" in accept:
+            parts = [gzip.compress(b"".join(parts), compresslevel=1)]
+            rh["Content-Encoding"] = "gzip"
+        elif "deflate" in accept:
+            parts = [zlib.compress(b"".join(parts), 1)]
+            rh["Content-Encoding"] = "deflate"
+        return 200, rh, parts
+
+
 class _HttpProtocol(asyncio.Protocol):
     def __init__(self, front):
         self.front = front
@@ -253,6 +389,7 @@ class _HttpProtocol(asyncio.Protocol):
 class HttpFront:
     def __init__(self, core, host="127.0.0.1", port=8000, workers=16, tls=None):
         self.core = core
+        self.router = Router(core)
         self.host = host
         self.port = port
         self._tls = tls  # (certificate chain, private key, client CA or None) as PEM file paths
@@ -292,99 +429,15 @@ class HttpFront:
 
     # ------------------------------------------------------------- routing
     async def dispatch(self, method, target, headers, body):
-        parts = urlsplit(target)
-        path = unquote(parts.path).strip("/")
-        query = parse_qs(parts.query)
-        core = self.core
-        if headers.get("content-encoding") == "gzip":
-            body = gzip.decompress(body)
-        elif headers.get("content-encoding") == "deflate":
-            body = zlib.decompress(body)
-
-        def ok(obj=None):
-            return 200, {}, [_dumps(obj) if obj is not None else b""]
-
-        if path == "v2/health/live":
-            return (200 if core.live else 400), {}, [b""]
-        if path == "v2/health/ready":
-            return (200 if core.ready else 400), {}, [b""]
-        if path == "v2":
-            return ok(core.server_metadata())
-        if path == "v2/models/stats":
-            return ok(core.statistics())
-        if path == "v2/repository/index":
-            ready = bool(json.loads(body).get("ready", False)) if body.strip() else False
-            return ok(core.repository_index(ready))
-        if path == "v2/trace/setting":
-            if method == "POST":
-                return ok(core.update_trace(None, json.loads(body) if body.strip() else {}))
-            return ok(core.get_trace(None))
-        if path == "v2/logging":
-            if method == "POST":
-                return ok(core.update_log(json.loads(body) if body.strip() else {}))
-            return ok(dict(core.log_settings))
-        m = _REPO_RE.match(path)
-        if m:
-            doc = json.loads(body) if body.strip() else {}
-            params = doc.get("parameters") or {}
-            loop = asyncio.get_running_loop()
-            if m["action"] == "load":
-                files = {k: v for k, v in params.items() if k.startswith("file:")}
-                await loop.run_in_executor(self.pool, core.load_model, m["model"], params.get("config"), files or None)
-            else:
-                await loop.run_in_executor(self.pool, core.unload_model, m["model"],
-                                           bool(params.get("unload_dependents", False)))
-            return ok()
-        m = _SHM_RE.match(path)
-        if m:
-            return self._shm(m["kind"], m["region"], m["action"], body, ok)
-        m = _MODEL_RE.match(path)
-        if m:
-            model, version, action = m["model"], m["version"] or "", m["action"]
-            if action is None:
-                return ok(core.model_metadata(model, version))
-            if action == "ready":
-                return (200 if core.is_model_ready(model, version) else 400), {}, [b""]
-            if action == "config":
-                return ok(core.model_config(model, version))
-            if action == "stats":
-                return ok(core.statistics(model, version))
-            if action == "trace/setting":
-                if method == "POST":
-                    return ok(core.update_trace(model, json.loads(body) if body.strip() else {}))
-                return ok(core.get_trace(model))
-            if action == "infer":
-                if method != "POST":
-                    raise ServerError("infer requires POST", 405)
-                return await self._infer(model, version, headers, body)
-        raise ServerError(f"no handler for {method} /{path}", 404)
-
-    def _shm(self, kind, region, action, body, ok):
-        core = self.core
-        reg = core.sysshm if kind == "systemsharedmemory" else core.devshm
-        if action == "status":
-            return ok(reg.status(region or ""))
-        if action == "unregister":
-            reg.unregister(region or "")
-            return ok()
-        if not region:
-            raise ServerError("register requires a region name", 400)
-        doc = json.loads(body) if body.strip() else {}
-        try:
-            if kind == "systemsharedmemory":
-                reg.register(region, doc["key"], int(doc.get("offset", 0)), int(doc["byte_size"]))
-            else:
-                import base64
-
-                raw = base64.b64decode(doc["raw_handle"]["b64"])
-                reg.register(region, raw, int(doc["device_id"]), int(doc["byte_size"]))
-        except KeyError as e:
-            raise ServerError(f"missing field {e} in shared memory register request", 400) from None
-        return ok()
+        routed = self.router.route(method, target, headers, body)
+        if routed[0] == "infer":
+            return await self._infer(routed[1], routed[2], headers, routed[3])
+        if routed[0] == "blocking":
+            return await asyncio.get_running_loop().run_in_executor(self.pool, routed[1])
+        return routed
 
     async def _infer(self, model, version, headers, body):
-        hl = headers.get("inference-header-content-length")
-        req = parse_infer_body(model, version, body, int(hl) if hl is not None else None)
+        req = self.router.parse_infer(model, version, headers, body)
         loop = asyncio.get_running_loop()
         if self.core.uses_batcher(model):
             # GPU model behind the dynamic batcher: queue from this thread, the completer
@@ -411,19 +464,4 @@ class HttpFront:
             resp = self.core.infer(req)
         else:
             resp = await loop.run_in_executor(self.pool, self.core.infer, req)
-        if not hasattr(resp, "outputs"):
-            raise ServerError(
-                f"model '{model}' is decoupled and can only be used through the gRPC streaming API", 400)
-        parts, json_len = render_infer_response(resp, getattr(req, "http_default_binary", False))
-        rh = {}
-        if json_len is not None:
-            rh["Inference-Header-Content-Length"] = str(json_len)
-            rh["Content-Type"] = "application/octet-stream"
-        accept = headers.get("accept-encoding", "")
-        if "gzip" in accept:
-            parts = [gzip.compress(b"".join(parts), compresslevel=1)]
-            rh["Content-Encoding"] = "gzip"
-        elif "deflate" in accept:
-            parts = [zlib.compress(b"".join(parts), 1)]
-            rh["Content-Encoding"] = "deflate"
-        return 200, rh, parts
+        return Router.render_infer(resp, req, headers)
