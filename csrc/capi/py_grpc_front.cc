@@ -8,7 +8,8 @@
 //   front.finish(call, status, message) # trailers (errors, end of a stream)
 //   front.stop()
 //
-// The callbacks run on the front's reactor threads with the GIL held:
+// The callbacks run with the GIL held - on the reactor thread when there is one
+// reactor, else on one funnel thread that serves all reactors (gil_funnel.h):
 //   on_unary(call, method, request_bytes), on_stream_message(call, method,
 //   request_bytes), on_stream_end(call), on_cancel(call).
 // A large ModelInfer request (tensors on the wire) is not copied into Python
@@ -21,11 +22,13 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+#include <memory>
 #include <set>
 #include <string>
 #include <utility>
 #include <vector>
 
+#include "gil_funnel.h"
 #include "tca/grpc_server.h"
 
 namespace {
@@ -37,6 +40,7 @@ struct PyGrpcFront {
   PyObject* on_stream_message;
   PyObject* on_stream_end;
   PyObject* on_cancel;
+  tca::capi::GilFunnel* funnel;  // null with one reactor: that thread calls Python itself
 };
 
 // Owns one received message and exposes it through the buffer protocol, so numpy
@@ -139,9 +143,9 @@ PyObject* tca_new_blob(std::string&& data) {
 
 namespace {
 
+// Calls fn(*args) with the GIL held.
 void CallPython(PyObject* fn, const char* fmt, ...) {
   if (fn == nullptr || fn == Py_None) return;
-  PyGILState_STATE gil = PyGILState_Ensure();
   va_list args;
   va_start(args, fmt);
   PyObject* packed = Py_VaBuildValue(fmt, args);
@@ -154,7 +158,54 @@ void CallPython(PyObject* fn, const char* fmt, ...) {
   } else {
     PyErr_WriteUnraisable(fn);
   }
+}
+
+// Runs `fn` with the GIL held: on the funnel thread when there is one, else here.
+template <typename Fn>
+void WithGil(PyGrpcFront* self, Fn&& fn) {
+  if (self->funnel != nullptr) {
+    self->funnel->Push(std::forward<Fn>(fn));
+    return;
+  }
+  PyGILState_STATE gil = PyGILState_Ensure();
+  fn();
   PyGILState_Release(gil);
+}
+
+// A unary request -> on_unary, with the GIL held.
+void DeliverUnary(PyGrpcFront* self, uint64_t call, const std::string& method, std::string& request);
+
+void DeliverUnary(PyGrpcFront* self, uint64_t call, const std::string& method, std::string& request) {
+  if (request.size() >= kZeroCopyThreshold && method == "ModelInfer") {
+    std::string head;
+    std::vector<std::pair<size_t, size_t>> spans;
+    if (SplitRawContents(request, &head, &spans) && !spans.empty()) {
+      auto* blob = PyObject_New(PyBlob, &kBlobType);
+      PyObject* list = blob ? PyTuple_New(static_cast<Py_ssize_t>(spans.size())) : nullptr;
+      if (blob != nullptr && list != nullptr) {
+        blob->data = new std::string(std::move(request));
+        for (size_t k = 0; k < spans.size(); ++k)
+          PyTuple_SET_ITEM(list, static_cast<Py_ssize_t>(k),
+                           Py_BuildValue("(nn)", static_cast<Py_ssize_t>(spans[k].first),
+                                         static_cast<Py_ssize_t>(spans[k].second)));
+        PyObject* result = PyObject_CallFunction(self->on_unary, "Ksy#OO", static_cast<unsigned long long>(call),
+                                                 method.c_str(), head.data(), static_cast<Py_ssize_t>(head.size()),
+                                                 reinterpret_cast<PyObject*>(blob), list);
+        if (result == nullptr) PyErr_WriteUnraisable(self->on_unary);
+        else Py_DECREF(result);
+      } else {
+        PyErr_Clear();
+      }
+      Py_XDECREF(list);
+      if (blob != nullptr) {
+        if (list == nullptr) blob->data = new std::string();  // allocation failed before ownership moved
+        Py_DECREF(reinterpret_cast<PyObject*>(blob));
+      }
+      return;
+    }
+  }
+  CallPython(self->on_unary, "(Ksy#)", static_cast<unsigned long long>(call), method.c_str(), request.data(),
+             static_cast<Py_ssize_t>(request.size()));
 }
 
 int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
@@ -193,48 +244,24 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   self->on_stream_end = on_end;
   self->on_cancel = on_cancel;
   tca::server::GrpcServerFront::Handlers h;
+  self->funnel = threads > 1 ? new tca::capi::GilFunnel() : nullptr;
   h.on_unary = [self](uint64_t call, const std::string& method, std::string&& request) {
-    if (request.size() >= kZeroCopyThreshold && method == "ModelInfer") {
-      std::string head;
-      std::vector<std::pair<size_t, size_t>> spans;
-      if (SplitRawContents(request, &head, &spans) && !spans.empty()) {
-        PyGILState_STATE gil = PyGILState_Ensure();
-        auto* blob = PyObject_New(PyBlob, &kBlobType);
-        PyObject* list = blob ? PyTuple_New(static_cast<Py_ssize_t>(spans.size())) : nullptr;
-        if (blob != nullptr && list != nullptr) {
-          blob->data = new std::string(std::move(request));
-          for (size_t k = 0; k < spans.size(); ++k)
-            PyTuple_SET_ITEM(list, static_cast<Py_ssize_t>(k),
-                             Py_BuildValue("(nn)", static_cast<Py_ssize_t>(spans[k].first),
-                                           static_cast<Py_ssize_t>(spans[k].second)));
-          PyObject* result = PyObject_CallFunction(self->on_unary, "Ksy#OO", static_cast<unsigned long long>(call),
-                                                   method.c_str(), head.data(), static_cast<Py_ssize_t>(head.size()),
-                                                   reinterpret_cast<PyObject*>(blob), list);
-          if (result == nullptr) PyErr_WriteUnraisable(self->on_unary);
-          else Py_DECREF(result);
-        } else {
-          PyErr_Clear();
-        }
-        Py_XDECREF(list);
-        if (blob != nullptr) {
-          if (list == nullptr) blob->data = new std::string();  // allocation failed before ownership moved
-          Py_DECREF(reinterpret_cast<PyObject*>(blob));
-        }
-        PyGILState_Release(gil);
-        return;
-      }
-    }
-    CallPython(self->on_unary, "(Ksy#)", static_cast<unsigned long long>(call), method.c_str(), request.data(),
-               static_cast<Py_ssize_t>(request.size()));
+    auto req = std::make_shared<std::string>(std::move(request));
+    WithGil(self, [self, call, method, req] { DeliverUnary(self, call, method, *req); });
   };
   h.on_stream_message = [self](uint64_t call, const std::string& method, std::string&& request) {
-    CallPython(self->on_stream_message, "(Ksy#)", static_cast<unsigned long long>(call), method.c_str(),
-               request.data(), static_cast<Py_ssize_t>(request.size()));
+    auto req = std::make_shared<std::string>(std::move(request));
+    WithGil(self, [self, call, method, req] {
+      CallPython(self->on_stream_message, "(Ksy#)", static_cast<unsigned long long>(call), method.c_str(), req->data(),
+                 static_cast<Py_ssize_t>(req->size()));
+    });
   };
   h.on_stream_end = [self](uint64_t call) {
-    CallPython(self->on_stream_end, "(K)", static_cast<unsigned long long>(call));
+    WithGil(self, [self, call] { CallPython(self->on_stream_end, "(K)", static_cast<unsigned long long>(call)); });
   };
-  h.on_cancel = [self](uint64_t call) { CallPython(self->on_cancel, "(K)", static_cast<unsigned long long>(call)); };
+  h.on_cancel = [self](uint64_t call) {
+    WithGil(self, [self, call] { CallPython(self->on_cancel, "(K)", static_cast<unsigned long long>(call)); });
+  };
   self->front = new tca::server::GrpcServerFront(host, port, threads, {"ModelStreamInfer"}, std::move(h));
   if (tls) self->front->SetTls(std::move(tls));
   return 0;
@@ -243,9 +270,11 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
 void StopFront(PyGrpcFront* self) {
   if (self->front == nullptr) return;
   tca::server::GrpcServerFront* front = self->front;
-  // reactor threads may be waiting for the GIL inside a callback: let them finish
+  tca::capi::GilFunnel* funnel = self->funnel;
+  // reactor / funnel threads may be waiting for the GIL inside a callback: let them finish
   Py_BEGIN_ALLOW_THREADS
   front->Stop();
+  if (funnel != nullptr) funnel->Stop();
   Py_END_ALLOW_THREADS
 }
 
@@ -254,6 +283,8 @@ void FrontDealloc(PyObject* self_obj) {
   StopFront(self);
   delete self->front;
   self->front = nullptr;
+  delete self->funnel;
+  self->funnel = nullptr;
   Py_XDECREF(self->on_unary);
   Py_XDECREF(self->on_stream_message);
   Py_XDECREF(self->on_stream_end);

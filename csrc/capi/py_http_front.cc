@@ -15,10 +15,12 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
 
+#include "gil_funnel.h"
 #include "tca/http_server.h"
 
 PyObject* tca_new_blob(std::string&& data);  // py_grpc_front.cc
@@ -30,9 +32,44 @@ struct PyHttpFront {
   tca::server::HttpServerFront* front;
   PyObject* on_request;
   PyObject* on_cancel;
+  tca::capi::GilFunnel* funnel;  // null with one reactor: that thread calls Python itself
 };
 
 constexpr size_t kZeroCopyThreshold = 128 * 1024;
+
+// Both run with the GIL held.
+void DeliverRequest(PyHttpFront* self, uint64_t call, tca::server::HttpServerFront::Request& req) {
+  PyObject* headers = PyDict_New();
+  PyObject* body = nullptr;
+  if (headers != nullptr) {
+    for (const auto& kv : req.headers) {
+      PyObject* v = PyUnicode_DecodeLatin1(kv.second.data(), static_cast<Py_ssize_t>(kv.second.size()), nullptr);
+      if (v == nullptr) break;
+      PyDict_SetItemString(headers, kv.first.c_str(), v);
+      Py_DECREF(v);
+    }
+    body = req.body.size() >= kZeroCopyThreshold
+               ? tca_new_blob(std::move(req.body))
+               : PyBytes_FromStringAndSize(req.body.data(), static_cast<Py_ssize_t>(req.body.size()));
+  }
+  if (headers != nullptr && body != nullptr && !PyErr_Occurred()) {
+    PyObject* result = PyObject_CallFunction(self->on_request, "KssOO", static_cast<unsigned long long>(call),
+                                             req.method.c_str(), req.target.c_str(), headers, body);
+    if (result == nullptr) PyErr_WriteUnraisable(self->on_request);
+    else Py_DECREF(result);
+  } else {
+    PyErr_Clear();
+    self->front->Respond(call, 500, {}, {std::string("{\"error\":\"out of memory\"}")});
+  }
+  Py_XDECREF(headers);
+  Py_XDECREF(body);
+}
+
+void DeliverCancel(PyHttpFront* self, uint64_t call) {
+  PyObject* result = PyObject_CallFunction(self->on_cancel, "K", static_cast<unsigned long long>(call));
+  if (result == nullptr) PyErr_WriteUnraisable(self->on_cancel);
+  else Py_DECREF(result);
+}
 
 int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   auto* self = reinterpret_cast<PyHttpFront*>(self_obj);
@@ -65,40 +102,25 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   self->on_request = on_request;
   self->on_cancel = on_cancel;
   tca::server::HttpServerFront::Handlers h;
+  self->funnel = threads > 1 ? new tca::capi::GilFunnel() : nullptr;
   h.on_request = [self](uint64_t call, tca::server::HttpServerFront::Request&& req) {
+    if (self->funnel != nullptr) {
+      auto shared = std::make_shared<tca::server::HttpServerFront::Request>(std::move(req));
+      self->funnel->Push([self, call, shared] { DeliverRequest(self, call, *shared); });
+      return;
+    }
     PyGILState_STATE gil = PyGILState_Ensure();
-    PyObject* headers = PyDict_New();
-    PyObject* body = nullptr;
-    if (headers != nullptr) {
-      for (const auto& kv : req.headers) {
-        PyObject* v = PyUnicode_DecodeLatin1(kv.second.data(), static_cast<Py_ssize_t>(kv.second.size()), nullptr);
-        if (v == nullptr) break;
-        PyDict_SetItemString(headers, kv.first.c_str(), v);
-        Py_DECREF(v);
-      }
-      body = req.body.size() >= kZeroCopyThreshold
-                 ? tca_new_blob(std::move(req.body))
-                 : PyBytes_FromStringAndSize(req.body.data(), static_cast<Py_ssize_t>(req.body.size()));
-    }
-    if (headers != nullptr && body != nullptr && !PyErr_Occurred()) {
-      PyObject* result = PyObject_CallFunction(self->on_request, "KssOO", static_cast<unsigned long long>(call),
-                                               req.method.c_str(), req.target.c_str(), headers, body);
-      if (result == nullptr) PyErr_WriteUnraisable(self->on_request);
-      else Py_DECREF(result);
-    } else {
-      PyErr_Clear();
-      self->front->Respond(call, 500, {}, {std::string("{\"error\":\"out of memory\"}")});
-    }
-    Py_XDECREF(headers);
-    Py_XDECREF(body);
+    DeliverRequest(self, call, req);
     PyGILState_Release(gil);
   };
   h.on_cancel = [self](uint64_t call) {
     if (self->on_cancel == nullptr || self->on_cancel == Py_None) return;
+    if (self->funnel != nullptr) {
+      self->funnel->Push([self, call] { DeliverCancel(self, call); });
+      return;
+    }
     PyGILState_STATE gil = PyGILState_Ensure();
-    PyObject* result = PyObject_CallFunction(self->on_cancel, "K", static_cast<unsigned long long>(call));
-    if (result == nullptr) PyErr_WriteUnraisable(self->on_cancel);
-    else Py_DECREF(result);
+    DeliverCancel(self, call);
     PyGILState_Release(gil);
   };
   self->front = new tca::server::HttpServerFront(host, port, threads, std::move(h));
@@ -109,9 +131,11 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
 void StopFront(PyHttpFront* self) {
   if (self->front == nullptr) return;
   tca::server::HttpServerFront* front = self->front;
-  // reactor threads may be waiting for the GIL inside a callback: let them finish
+  tca::capi::GilFunnel* funnel = self->funnel;
+  // reactor / funnel threads may be waiting for the GIL inside a callback: let them finish
   Py_BEGIN_ALLOW_THREADS
   front->Stop();
+  if (funnel != nullptr) funnel->Stop();
   Py_END_ALLOW_THREADS
 }
 
@@ -120,6 +144,8 @@ void FrontDealloc(PyObject* self_obj) {
   StopFront(self);
   delete self->front;
   self->front = nullptr;
+  delete self->funnel;
+  self->funnel = nullptr;
   Py_XDECREF(self->on_request);
   Py_XDECREF(self->on_cancel);
   Py_TYPE(self_obj)->tp_free(self_obj);

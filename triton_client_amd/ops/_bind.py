@@ -161,3 +161,15 @@ def install_rt(lib):
     lib.tca_hip_memcpy_async.argtypes = [c_void_p, c_void_p, c_uint64, c_int, c_void_p]
     lib.tca_hip_memset_async.restype = c_int
     lib.tca_hip_memset_async.argtypes = [c_void_p, c_int, c_uint64, c_void_p]
+    if hasattr(lib, "tca_stager_create"):
+        lib.tca_stager_error.restype = c_char_p
+        lib.tca_stager_error.argtypes = []
+        lib.tca_stager_create.restype = c_int
+        lib.tca_stager_create.argtypes = [c_int, c_uint64, c_int, c_uint64, POINTER(c_void_p)]
+        lib.tca_stager_stage.restype = c_int
+        lib.tca_stager_stage.argtypes = [c_void_p, c_int, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64), c_void_p,
+                                         c_void_p]
+        lib.tca_stager_stats.restype = c_int
+        lib.tca_stager_stats.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]
+        lib.tca_stager_destroy.restype = c_int
+        lib.tca_stager_destroy.argtypes = [c_void_p]

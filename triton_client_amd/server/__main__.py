@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
 import signal
 import sys
 import threading
@@ -43,6 +44,8 @@ def main(argv=None):
         models = list(DEFAULT_CPU_MODELS)
         if args.gpu is not None:
             models += [n for n, c in MODEL_ZOO.items() if c.device == "gpu" and getattr(c, "autoload", True)]
+    if os.environ.get("TCA_SWITCH_INTERVAL_US"):
+        sys.setswitchinterval(float(os.environ["TCA_SWITCH_INTERVAL_US"]) * 1e-6)
     server = Server(models=models, gpu=args.gpu, http_port=args.http_port, grpc_port=args.grpc_port, host=args.host,
                     model_control=args.model_control_mode, http_workers=args.http_workers,
                     grpc_workers=args.grpc_workers, grpc_impl=args.grpc_impl, grpc_reactors=args.grpc_reactors, http_impl=args.http_impl,

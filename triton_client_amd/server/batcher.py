@@ -105,9 +105,7 @@ class DynamicBatcher:
         self.split_min_batch = int(os.environ.get("TCA_SPLIT_MIN_BATCH", getattr(self.model, "split_min_batch", 16)))
         self._busy_lock = threading.Lock()
         # per instance: [ring of [pinned uint8 buffer, event of its last H2D copy, bytes used], next entry]
-        self._pinned = [[[], 0] for _ in range(self.instances)]
-        self._pinned_bytes = 0
-        self._upload = [None] * self.instances  # per instance: copy stream + device-side staging buffers
+        self._stagers = [None] * self.instances  # per instance: native wire stager (pinned ring + copy stream)
         self.q = queue.Queue()
         self.completions = [queue.Queue() for _ in range(self.instances)]
         self._held = None
@@ -461,78 +459,23 @@ class DynamicBatcher:
         COPY stream into a device-side staging buffer, and the compute stream only does a
         device-to-device copy of the finished rows (microseconds) once they have landed: the
         upload of the next batch overlaps the forward of the current one instead of queueing
-        behind it on the compute stream, and the pinned ring is recycled at H2D speed."""
-        import torch
-
+        behind it on the compute stream, and the pinned ring is recycled at H2D speed.
+        The whole sequence is one native call (``csrc/hip/wire_stager.cc``) that runs without
+        the interpreter lock; this thread only decides which array goes to which rows."""
         if not items:
             return
-        srcs = [torch.from_numpy(np.ascontiguousarray(arr)) for arr, _, _ in items]
-        sizes = [t.numel() * t.element_size() for t in srcs]
-        state = self._pinned[inst]
-        ring = state[0]
-        need = max(sizes)
-        if not ring or need > ring[0][0].numel():
-            # (re)allocate.  Deliberately small - a few entries of one request each: the ring
-            # then stays resident in the CPU's last-level cache, which was measured to make
-            # the staging memcpy (and with it the whole wire path) almost twice as fast as
-            # cycling through batch-sized buffers.  An entry is recycled as soon as the H2D
-            # copy that read it is done (tens of microseconds).
-            per_entry = max(need, self._pinned_bytes)
-            self._pinned_bytes = per_entry
-            ring[:] = [[torch.empty(per_entry, dtype=torch.uint8, pin_memory=True), None, 0] for _ in range(4)]
-            state[1] = 0
-        up = self._upload[inst]
-        if up is None or up["bufs"][0].dtype != sbuf.dtype or tuple(up["bufs"][0].shape[1:]) != tuple(sbuf.shape[1:]):
-            device = sbuf.device
-            up = self._upload[inst] = {
-                "stream": torch.cuda.Stream(device=device),
-                "bufs": [torch.empty((self.max_batch, *sbuf.shape[1:]), dtype=sbuf.dtype, device=device) for _ in range(2)],
-                "free": [None, None],  # event after the compute stream's last read of each buffer
-                "next": 0,
-            }
-        slot = up["next"]
-        up["next"] = slot ^ 1
-        dev = up["bufs"][slot]
-        copy_stream = up["stream"]
-        if up["free"][slot] is not None:
-            copy_stream.wait_event(up["free"][slot])  # GPU-side: the batch that used this buffer two uploads ago
-        # One tensor at a time: reserve a ring slot (waiting for the H2D copy that last read
-        # it), memcpy, issue the H2D copy, mark the slot.  Serial memcpys on purpose (a thread
-        # pool here was measured to halve the wire throughput: the extra threads fight the
-        # transport callbacks for the GIL); the DMA of one tensor overlaps the memcpy of the next.
-        with torch.cuda.stream(copy_stream):
-            for (_, row, rows), src, nbytes in zip(items, srcs, sizes):
-                entry = ring[state[1]]
-                if entry[1] is None or entry[2] + nbytes > entry[0].numel():
-                    if entry[1] is not None:  # full: move on and wait for the next entry's last reader
-                        state[1] = (state[1] + 1) % len(ring)
-                        entry = ring[state[1]]
-                        if entry[1] is not None:
-                            entry[1].synchronize()
-                    entry[1] = torch.cuda.Event()
-                    entry[2] = 0
-                off = entry[2]
-                host = entry[0][off: off + nbytes].view(src.dtype).view(src.shape)
-                entry[2] = (off + nbytes + 255) & ~255
-                host.copy_(src)
-                dev[row: row + rows].copy_(host, non_blocking=True)
-                entry[1].record(copy_stream)  # the latest reader of this entry
-        landed = torch.cuda.Event()
-        landed.record(copy_stream)
-        stream.wait_event(landed)
-        with torch.cuda.stream(stream):
-            # merge neighbouring row ranges: a batch made only of wire requests is one copy
-            run_start, run_end = items[0][1], items[0][1] + items[0][2]
-            for _, row, rows in items[1:]:
-                if row == run_end:
-                    run_end = row + rows
-                    continue
-                sbuf[run_start:run_end].copy_(dev[run_start:run_end], non_blocking=True)
-                run_start, run_end = row, row + rows
-            sbuf[run_start:run_end].copy_(dev[run_start:run_end], non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(stream)
-        up["free"][slot] = done
+        from ..ops.staging import WireStager, as_staging_source
+
+        arrays = [as_staging_source(arr) for arr, _, _ in items]
+        row_bytes = sbuf[0].numel() * sbuf.element_size()
+        stager = self._stagers[inst]
+        if stager is None:
+            # a few ring entries of one request each: the ring then stays resident in the CPU's
+            # last-level cache, which was measured to make the staging memcpy (and with it the
+            # whole wire path) almost twice as fast as cycling through batch-sized buffers
+            stager = self._stagers[inst] = WireStager(sbuf.device.index or 0, max(a.nbytes for a in arrays),
+                                                      self.max_batch * row_bytes, entries=4)
+        stager.stage(arrays, [row * row_bytes for _, row, _ in items], sbuf.data_ptr(), stream)
 
     def _host_copies(self, it, result, stream, own_static):
         """Enqueue D2H copies (pinned) for outputs that go back over the wire,
