@@ -53,12 +53,12 @@ def parse_args():
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the short wire / system-shared-memory comparison runs")
-    ap.add_argument("--extra-requests", type=int, default=1536,
+    ap.add_argument("--extra-requests", type=int, default=4608,
                     help="requests per GPU of each comparison run (wire, system shm)")
     ap.add_argument("--client", choices=["native", "python"], default=os.environ.get("TCA_BENCH_CLIENT", "native"),
                     help="native: C++ load generator (tca_loadgen) over the in-tree gRPC/HTTP client; "
                          "python: tritonclient-API threads in this process")
-    ap.add_argument("--connections", type=int, default=4, help="gRPC channels the native load generator spreads over")
+    ap.add_argument("--connections", type=int, default=8, help="gRPC channels the native load generator spreads over")
     ap.add_argument("--image-requests", type=int, default=3000,
                     help="requests of the end-to-end image pipeline run (extra.image_client)")
     ap.add_argument("--image-lanes", type=int, default=3)

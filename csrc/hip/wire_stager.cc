@@ -20,9 +20,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -38,6 +43,91 @@ int Fail(const char* what, hipError_t e) {
     hipError_t _e = (expr);                      \
     if (_e != hipSuccess) return Fail(what, _e); \
   } while (0)
+
+// Splits one large host copy over a few persistent helper threads (plus the caller): one core
+// moves 6-7 GB/s into page-locked memory, which made this copy the bottleneck of the wire path
+// (a batch of sixteen 1.2 MB requests took 2.9 ms); four cores keep up with the H2D engine.
+class CopyPool {
+ public:
+  explicit CopyPool(int helpers) {
+    for (int i = 0; i < helpers; ++i) threads_.emplace_back([this] { Run(); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      ++generation_;
+    }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+
+  void Copy(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (threads_.empty() || n < 2 * kChunk) {
+      std::memcpy(dst, src, n);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      dst_ = dst;
+      src_ = src;
+      total_ = n;
+      next_.store(0, std::memory_order_relaxed);
+      working_ = static_cast<int>(threads_.size());
+      ++generation_;
+    }
+    cv_.notify_all();
+    Drain();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return working_ == 0; });
+  }
+
+ private:
+  static constexpr size_t kChunk = 128 * 1024;
+
+  void Drain() {
+    for (;;) {
+      const size_t off = next_.fetch_add(kChunk, std::memory_order_relaxed);
+      if (off >= total_) return;
+      std::memcpy(dst_ + off, src_ + off, std::min(kChunk, total_ - off));
+    }
+  }
+
+  void Run() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+      }
+      Drain();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        --working_;
+      }
+      done_cv_.notify_one();
+    }
+  }
+
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  uint8_t* dst_ = nullptr;
+  const uint8_t* src_ = nullptr;
+  size_t total_ = 0;
+  std::atomic<size_t> next_{0};
+  int working_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
+int HelperThreads() {
+  if (const char* env = std::getenv("TCA_STAGER_THREADS")) return std::max(0, std::min(15, std::atoi(env) - 1));
+  const unsigned cores = std::thread::hardware_concurrency();
+  return cores >= 16 ? 3 : (cores >= 8 ? 1 : 0);
+}
 
 struct RingEntry {
   uint8_t* host = nullptr;
@@ -59,6 +149,7 @@ struct Stager {
   hipEvent_t landed = nullptr;
   int next = 0;
   uint64_t staged_bytes = 0, staged_tensors = 0, ring_waits = 0;
+  CopyPool pool{HelperThreads()};
 
   int FreeRing() {
     for (auto& e : ring) {
@@ -189,7 +280,7 @@ int tca_stager_stage(void* handle, int count, const void* const* srcs, const uin
     }
     uint8_t* host = e->host + e->used;
     e->used = (e->used + sizes[i] + 255) & ~uint64_t(255);
-    std::memcpy(host, srcs[i], sizes[i]);
+    s->pool.Copy(host, static_cast<const uint8_t*>(srcs[i]), sizes[i]);
     ST_TRY(hipMemcpyAsync(dev + offsets[i], host, sizes[i], hipMemcpyHostToDevice, s->copy_stream), "hipMemcpyAsync(H2D)");
     ST_TRY(hipEventRecord(e->read, s->copy_stream), "hipEventRecord");  // the latest reader of this entry
     e->in_use = true;
