@@ -30,6 +30,9 @@
 
 #include "gil_funnel.h"
 #include "tca/grpc_server.h"
+#include "tca/native_executor.h"
+
+std::shared_ptr<tca::server::NativeExecutor> tca_native_from_py(PyObject* obj);  // py_native_executor.cc
 
 namespace {
 
@@ -41,6 +44,7 @@ struct PyGrpcFront {
   PyObject* on_stream_end;
   PyObject* on_cancel;
   tca::capi::GilFunnel* funnel;  // null with one reactor: that thread calls Python itself
+  std::shared_ptr<tca::server::NativeExecutor>* native;  // null: every request goes to Python
 };
 
 // Owns one received message and exposes it through the buffer protocol, so numpy
@@ -215,11 +219,13 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   PyObject *on_unary, *on_msg, *on_end, *on_cancel;
   // optional TLS: server certificate chain + key (PEM files); client_ca makes client certificates mandatory
   const char *tls_cert = nullptr, *tls_key = nullptr, *tls_client_ca = nullptr;
+  PyObject* native = nullptr;
   static const char* kwlist[] = {"host", "port", "threads", "on_unary", "on_stream_message", "on_stream_end",
-                                 "on_cancel", "tls_cert", "tls_key", "tls_client_ca", nullptr};
-  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "siiOOOO|zzz", const_cast<char**>(kwlist), &host, &port, &threads,
-                                   &on_unary, &on_msg, &on_end, &on_cancel, &tls_cert, &tls_key, &tls_client_ca))
+                                 "on_cancel", "tls_cert", "tls_key", "tls_client_ca", "native", nullptr};
+  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "siiOOOO|zzzO", const_cast<char**>(kwlist), &host, &port, &threads,
+                                   &on_unary, &on_msg, &on_end, &on_cancel, &tls_cert, &tls_key, &tls_client_ca, &native))
     return -1;
+  if (auto ex = tca_native_from_py(native)) self->native = new std::shared_ptr<tca::server::NativeExecutor>(std::move(ex));
   std::shared_ptr<tca::net::TlsContext> tls;
   if (tls_cert != nullptr || tls_key != nullptr) {
     tca::net::TlsOptions opt;
@@ -246,6 +252,13 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   tca::server::GrpcServerFront::Handlers h;
   self->funnel = threads > 1 ? new tca::capi::GilFunnel() : nullptr;
   h.on_unary = [self](uint64_t call, const std::string& method, std::string&& request) {
+    if (self->native != nullptr && method == "ModelInfer") {
+      std::string response;
+      if ((*self->native)->TryGrpc(request, &response)) {  // answered on this reactor thread, no interpreter
+        self->front->Reply(call, std::move(response));
+        return;
+      }
+    }
     auto req = std::make_shared<std::string>(std::move(request));
     WithGil(self, [self, call, method, req] { DeliverUnary(self, call, method, *req); });
   };
@@ -285,6 +298,8 @@ void FrontDealloc(PyObject* self_obj) {
   self->front = nullptr;
   delete self->funnel;
   self->funnel = nullptr;
+  delete self->native;
+  self->native = nullptr;
   Py_XDECREF(self->on_unary);
   Py_XDECREF(self->on_stream_message);
   Py_XDECREF(self->on_stream_end);

@@ -15,6 +15,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <utility>
@@ -22,8 +23,10 @@
 
 #include "gil_funnel.h"
 #include "tca/http_server.h"
+#include "tca/native_executor.h"
 
 PyObject* tca_new_blob(std::string&& data);  // py_grpc_front.cc
+std::shared_ptr<tca::server::NativeExecutor> tca_native_from_py(PyObject* obj);  // py_native_executor.cc
 
 namespace {
 
@@ -33,7 +36,52 @@ struct PyHttpFront {
   PyObject* on_request;
   PyObject* on_cancel;
   tca::capi::GilFunnel* funnel;  // null with one reactor: that thread calls Python itself
+  std::shared_ptr<tca::server::NativeExecutor>* native;  // null: every request goes to Python
 };
+
+// "/v2/models/<name>[/versions/<v>]/infer" -> name, version; false for every other target.
+bool InferTarget(const std::string& target, std::string* model, std::string* version) {
+  static const std::string kPrefix = "/v2/models/";
+  static const std::string kSuffix = "/infer";
+  if (target.compare(0, kPrefix.size(), kPrefix) != 0 || target.size() <= kPrefix.size() + kSuffix.size() ||
+      target.compare(target.size() - kSuffix.size(), kSuffix.size(), kSuffix) != 0 ||
+      target.find_first_of("?%") != std::string::npos)
+    return false;
+  const std::string mid = target.substr(kPrefix.size(), target.size() - kPrefix.size() - kSuffix.size());
+  const size_t slash = mid.find('/');
+  if (slash == std::string::npos) {
+    *model = mid;
+    version->clear();
+    return !model->empty();
+  }
+  static const std::string kVersions = "/versions/";
+  if (mid.compare(slash, kVersions.size(), kVersions) != 0) return false;
+  *model = mid.substr(0, slash);
+  *version = mid.substr(slash + kVersions.size());
+  return !model->empty() && !version->empty() && version->find('/') == std::string::npos;
+}
+
+// True when the native path answered the request.
+bool TryNative(PyHttpFront* self, uint64_t call, const tca::server::HttpServerFront::Request& req) {
+  if (self->native == nullptr || req.method != "POST") return false;
+  std::string model, version;
+  if (!InferTarget(req.target, &model, &version)) return false;
+  int64_t header_length = -1;
+  for (const auto& h : req.headers) {
+    if (h.first == "content-encoding" || h.first == "accept-encoding") {
+      if (h.second.find("gzip") != std::string::npos || h.second.find("deflate") != std::string::npos) return false;
+    } else if (h.first == "inference-header-content-length") {
+      char* stop = nullptr;
+      header_length = std::strtoll(h.second.c_str(), &stop, 10);
+      if (h.second.empty() || *stop != '\0' || header_length < 0) return false;
+    }
+  }
+  tca::server::HttpServerFront::HeaderList headers;
+  std::vector<std::string> parts;
+  if (!(*self->native)->TryHttp(model, version, req.body, header_length, &headers, &parts)) return false;
+  self->front->Respond(call, 200, std::move(headers), std::move(parts));
+  return true;
+}
 
 constexpr size_t kZeroCopyThreshold = 128 * 1024;
 
@@ -77,11 +125,13 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   int port = 0, threads = 2;
   PyObject *on_request, *on_cancel;
   const char *tls_cert = nullptr, *tls_key = nullptr, *tls_client_ca = nullptr;
+  PyObject* native = nullptr;
   static const char* kwlist[] = {"host", "port", "threads", "on_request", "on_cancel", "tls_cert", "tls_key",
-                                 "tls_client_ca", nullptr};
-  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "siiOO|zzz", const_cast<char**>(kwlist), &host, &port, &threads,
-                                   &on_request, &on_cancel, &tls_cert, &tls_key, &tls_client_ca))
+                                 "tls_client_ca", "native", nullptr};
+  if (!PyArg_ParseTupleAndKeywords(args, kwargs, "siiOO|zzzO", const_cast<char**>(kwlist), &host, &port, &threads,
+                                   &on_request, &on_cancel, &tls_cert, &tls_key, &tls_client_ca, &native))
     return -1;
+  if (auto ex = tca_native_from_py(native)) self->native = new std::shared_ptr<tca::server::NativeExecutor>(std::move(ex));
   std::shared_ptr<tca::net::TlsContext> tls;
   if (tls_cert != nullptr || tls_key != nullptr) {
     tca::net::TlsOptions opt;
@@ -104,6 +154,7 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   tca::server::HttpServerFront::Handlers h;
   self->funnel = threads > 1 ? new tca::capi::GilFunnel() : nullptr;
   h.on_request = [self](uint64_t call, tca::server::HttpServerFront::Request&& req) {
+    if (TryNative(self, call, req)) return;  // answered on this reactor thread, no interpreter
     if (self->funnel != nullptr) {
       auto shared = std::make_shared<tca::server::HttpServerFront::Request>(std::move(req));
       self->funnel->Push([self, call, shared] { DeliverRequest(self, call, *shared); });
@@ -146,6 +197,8 @@ void FrontDealloc(PyObject* self_obj) {
   self->front = nullptr;
   delete self->funnel;
   self->funnel = nullptr;
+  delete self->native;
+  self->native = nullptr;
   Py_XDECREF(self->on_request);
   Py_XDECREF(self->on_cancel);
   Py_TYPE(self_obj)->tp_free(self_obj);

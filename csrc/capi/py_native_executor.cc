@@ -1,0 +1,207 @@
+// Python binding of the native execution path (`_tca_pyext.NativeExecutor`).
+//
+//   ex = NativeExecutor()
+//   ex.set_model(name, version, max_batch, [(name, datatype, dims), ...], [(name, datatype, dims), ...], kernel)
+//   ex.remove_model(name)
+//   ex.register_region(name, key, offset, byte_size) / ex.unregister_region(name)   # "" = all
+//   ex.take_stats(name) -> None | {"requests", "inferences", "queue_ns", "last_ms", "by_batch": {b: (count, in, infer, out)}}
+//   ex.set_enabled(flag); ex.counters() -> {"handled", "declined"}
+//
+// The serving fronts take the object as their `native=` argument and offer it every inference
+// request before Python sees it (tca/native_executor.h).
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+
+#include <memory>
+#include <string>
+
+#include "tca/native_executor.h"
+
+namespace {
+
+struct PyNativeExecutor {
+  PyObject_HEAD
+  std::shared_ptr<tca::server::NativeExecutor>* ex;
+};
+
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wmissing-field-initializers"
+PyTypeObject kType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+#pragma GCC diagnostic pop
+
+int Init(PyObject* self_obj, PyObject*, PyObject*) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  delete self->ex;
+  self->ex = new std::shared_ptr<tca::server::NativeExecutor>(new tca::server::NativeExecutor());
+  return 0;
+}
+
+void Dealloc(PyObject* self_obj) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  delete self->ex;
+  self->ex = nullptr;
+  Py_TYPE(self_obj)->tp_free(self_obj);
+}
+
+bool ParseTensors(PyObject* list, std::vector<tca::server::NativeExecutor::TensorSpec>* out) {
+  PyObject* seq = PySequence_Fast(list, "tensor specs must be a sequence of (name, datatype, dims)");
+  if (seq == nullptr) return false;
+  for (Py_ssize_t i = 0; i < PySequence_Fast_GET_SIZE(seq); ++i) {
+    const char *name = nullptr, *dt = nullptr;
+    PyObject* dims = nullptr;
+    if (!PyArg_ParseTuple(PySequence_Fast_GET_ITEM(seq, i), "ssO", &name, &dt, &dims)) {
+      Py_DECREF(seq);
+      return false;
+    }
+    tca::server::NativeExecutor::TensorSpec t;
+    t.name = name;
+    t.datatype = dt;
+    PyObject* dseq = PySequence_Fast(dims, "dims must be a sequence of integers");
+    if (dseq == nullptr) {
+      Py_DECREF(seq);
+      return false;
+    }
+    for (Py_ssize_t k = 0; k < PySequence_Fast_GET_SIZE(dseq); ++k) {
+      const long long v = PyLong_AsLongLong(PySequence_Fast_GET_ITEM(dseq, k));
+      if (v == -1 && PyErr_Occurred()) {
+        Py_DECREF(dseq);
+        Py_DECREF(seq);
+        return false;
+      }
+      t.dims.push_back(v);
+    }
+    Py_DECREF(dseq);
+    out->push_back(std::move(t));
+  }
+  Py_DECREF(seq);
+  return true;
+}
+
+PyObject* SetModel(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char *name = nullptr, *version = nullptr, *kernel = nullptr;
+  int max_batch = 0;
+  PyObject *inputs = nullptr, *outputs = nullptr;
+  if (!PyArg_ParseTuple(args, "ssiOOs", &name, &version, &max_batch, &inputs, &outputs, &kernel)) return nullptr;
+  tca::server::NativeExecutor::ModelSpec spec;
+  spec.name = name;
+  spec.version = version;
+  spec.max_batch = max_batch;
+  spec.kernel = kernel;
+  if (!ParseTensors(inputs, &spec.inputs) || !ParseTensors(outputs, &spec.outputs)) return nullptr;
+  const tca::Error e = (*self->ex)->SetModel(spec);
+  if (!e.IsOk()) {
+    PyErr_SetString(PyExc_ValueError, e.Message().c_str());
+    return nullptr;
+  }
+  Py_RETURN_NONE;
+}
+
+PyObject* RemoveModel(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = nullptr;
+  if (!PyArg_ParseTuple(args, "s", &name)) return nullptr;
+  (*self->ex)->RemoveModel(name);
+  Py_RETURN_NONE;
+}
+
+PyObject* RegisterRegion(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char *name = nullptr, *key = nullptr;
+  unsigned long long offset = 0, size = 0;
+  if (!PyArg_ParseTuple(args, "ssKK", &name, &key, &offset, &size)) return nullptr;
+  const tca::Error e = (*self->ex)->RegisterRegion(name, key, offset, size);
+  if (!e.IsOk()) {
+    PyErr_SetString(PyExc_ValueError, e.Message().c_str());
+    return nullptr;
+  }
+  Py_RETURN_NONE;
+}
+
+PyObject* UnregisterRegion(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = "";
+  if (!PyArg_ParseTuple(args, "|s", &name)) return nullptr;
+  (*self->ex)->UnregisterRegion(name);
+  Py_RETURN_NONE;
+}
+
+PyObject* TakeStats(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = nullptr;
+  if (!PyArg_ParseTuple(args, "s", &name)) return nullptr;
+  tca::server::NativeExecutor::Stats st;
+  if (!(*self->ex)->TakeStats(name, &st)) Py_RETURN_NONE;
+  PyObject* by_batch = PyDict_New();
+  if (by_batch == nullptr) return nullptr;
+  for (const auto& kv : st.by_batch) {
+    PyObject* key = PyLong_FromLong(kv.first);
+    PyObject* val = Py_BuildValue("(KKKK)", static_cast<unsigned long long>(kv.second.count),
+                                  static_cast<unsigned long long>(kv.second.input_ns),
+                                  static_cast<unsigned long long>(kv.second.infer_ns),
+                                  static_cast<unsigned long long>(kv.second.output_ns));
+    if (key == nullptr || val == nullptr || PyDict_SetItem(by_batch, key, val) < 0) {
+      Py_XDECREF(key);
+      Py_XDECREF(val);
+      Py_DECREF(by_batch);
+      return nullptr;
+    }
+    Py_DECREF(key);
+    Py_DECREF(val);
+  }
+  return Py_BuildValue("{s:K,s:K,s:K,s:K,s:N}", "requests", static_cast<unsigned long long>(st.requests), "inferences",
+                       static_cast<unsigned long long>(st.inferences), "queue_ns",
+                       static_cast<unsigned long long>(st.queue_ns), "last_ms",
+                       static_cast<unsigned long long>(st.last_ms), "by_batch", by_batch);
+}
+
+PyObject* SetEnabled(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  int on = 1;
+  if (!PyArg_ParseTuple(args, "p", &on)) return nullptr;
+  (*self->ex)->SetEnabled(on != 0);
+  Py_RETURN_NONE;
+}
+
+PyObject* Counters(PyObject* self_obj, PyObject*) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  return Py_BuildValue("{s:K,s:K}", "handled", static_cast<unsigned long long>((*self->ex)->Handled()), "declined",
+                       static_cast<unsigned long long>((*self->ex)->Declined()));
+}
+
+PyMethodDef kMethods[] = {
+    {"set_model", SetModel, METH_VARARGS, "set_model(name, version, max_batch, inputs, outputs, kernel)"},
+    {"remove_model", RemoveModel, METH_VARARGS, "remove_model(name)"},
+    {"register_region", RegisterRegion, METH_VARARGS, "register_region(name, key, offset, byte_size)"},
+    {"unregister_region", UnregisterRegion, METH_VARARGS, "unregister_region([name]): all regions without a name"},
+    {"take_stats", TakeStats, METH_VARARGS, "take_stats(name): statistics accumulated since the last call, or None"},
+    {"set_enabled", SetEnabled, METH_VARARGS, "set_enabled(flag)"},
+    {"counters", Counters, METH_NOARGS, "requests handled natively / looked at and handed on"},
+    {nullptr, nullptr, 0, nullptr}};
+
+}  // namespace
+
+// The executor behind a Python NativeExecutor object, or null when `obj` is None / another type.
+std::shared_ptr<tca::server::NativeExecutor> tca_native_from_py(PyObject* obj) {
+  if (obj == nullptr || obj == Py_None || !PyObject_TypeCheck(obj, &kType)) return nullptr;
+  auto* self = reinterpret_cast<PyNativeExecutor*>(obj);
+  return self->ex ? *self->ex : nullptr;
+}
+
+extern "C" int tca_register_native_executor(PyObject* module) {
+  kType.tp_name = "_tca_pyext.NativeExecutor";
+  kType.tp_basicsize = sizeof(PyNativeExecutor);
+  kType.tp_flags = Py_TPFLAGS_DEFAULT;
+  kType.tp_doc = "Native execution path for models with a C++ kernel.";
+  kType.tp_new = PyType_GenericNew;
+  kType.tp_init = Init;
+  kType.tp_dealloc = Dealloc;
+  kType.tp_methods = kMethods;
+  if (PyType_Ready(&kType) < 0) return -1;
+  Py_INCREF(&kType);
+  if (PyModule_AddObject(module, "NativeExecutor", reinterpret_cast<PyObject*>(&kType)) < 0) {
+    Py_DECREF(&kType);
+    return -1;
+  }
+  return 0;
+}

@@ -191,11 +191,13 @@ static struct PyModuleDef kModule = {PyModuleDef_HEAD_INIT, "_tca_pyext", "nativ
 
 extern "C" int tca_register_grpc_front(PyObject* module);  // py_grpc_front.cc
 extern "C" int tca_register_http_front(PyObject* module);  // py_http_front.cc
+extern "C" int tca_register_native_executor(PyObject* module);  // py_native_executor.cc
 
 PyMODINIT_FUNC PyInit__tca_pyext(void) {
   PyObject* module = PyModule_Create(&kModule);
   if (module == nullptr) return nullptr;
-  if (tca_register_grpc_front(module) < 0 || tca_register_http_front(module) < 0) {
+  if (tca_register_grpc_front(module) < 0 || tca_register_http_front(module) < 0 ||
+      tca_register_native_executor(module) < 0) {
     Py_DECREF(module);
     return nullptr;
   }

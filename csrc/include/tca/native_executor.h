@@ -1,0 +1,102 @@
+// Native execution path of the in-repo server for models whose kernel exists in C++.
+//
+// The serving fronts hand every inference request to TryGrpc / TryHttp first, on the
+// reactor thread that received it.  When the model is registered here and the request
+// is completely ordinary (no request parameters, tensors on the wire or in system
+// shared memory, shapes and types that match the model) it is decoded, executed and
+// answered without the Python interpreter; anything else - including every request
+// that would be an error - returns false and takes the general path, which also
+// produces the error texts.  Microsecond-scale CPU models are bound by the
+// interpreter lock otherwise (about 25 us of Python per request).
+//
+// Kernels: "add_sub" (OUTPUT0 = INPUT0 + INPUT1, OUTPUT1 = INPUT0 - INPUT1, any integer
+// or floating type; the `simple` model family the reference's examples and perf tools
+// are written against, e.g. `src/c++/examples/simple_http_infer_client.cc:127-160`) and
+// "identity" (OUTPUT0 = INPUT0).
+//
+// Statistics are accumulated here and collected by the Python core (TakeStats), so the
+// model statistics endpoints keep counting requests that never reached Python.
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tca/error.h"
+
+namespace tca {
+namespace server {
+
+class NativeExecutor {
+ public:
+  struct TensorSpec {
+    std::string name, datatype;
+    std::vector<int64_t> dims;  // without the batch dimension; -1 = any
+  };
+  struct ModelSpec {
+    std::string name, version;  // version = the one unversioned requests resolve to
+    int max_batch = 0;
+    std::vector<TensorSpec> inputs, outputs;
+    std::string kernel;  // "add_sub" | "identity"
+  };
+  struct BatchStats {
+    uint64_t count = 0, input_ns = 0, infer_ns = 0, output_ns = 0;
+  };
+  struct Stats {
+    uint64_t requests = 0, inferences = 0, queue_ns = 0, last_ms = 0;
+    std::map<int, BatchStats> by_batch;
+  };
+  using HeaderList = std::vector<std::pair<std::string, std::string>>;
+
+  Error SetModel(const ModelSpec& spec);
+  void RemoveModel(const std::string& name);
+  // A window [offset, offset + size) of the POSIX shared-memory object `key`.
+  Error RegisterRegion(const std::string& name, const std::string& key, uint64_t offset, uint64_t size);
+  void UnregisterRegion(const std::string& name);  // "" = all
+  void SetEnabled(bool on) { enabled_.store(on); }
+
+  // `request` = serialized ModelInferRequest; true: `response` holds the serialized ModelInferResponse.
+  bool TryGrpc(const std::string& request, std::string* response);
+  // `body` = JSON header (+ binary tensors when `header_length` >= 0); true: answer in headers / parts.
+  bool TryHttp(const std::string& model, const std::string& version, const std::string& body, int64_t header_length,
+               HeaderList* headers, std::vector<std::string>* parts);
+
+  // Moves the statistics accumulated for `name` since the last call into `out`; false if there are none.
+  bool TakeStats(const std::string& name, Stats* out);
+  uint64_t Handled() const { return handled_.load(); }
+  uint64_t Declined() const { return declined_.load(); }
+
+ private:
+  struct Region {
+    uint8_t* base = nullptr;  // first byte of the window
+    uint64_t size = 0;
+    void* map = nullptr;
+    uint64_t map_size = 0;
+    ~Region();
+  };
+  struct Model {
+    ModelSpec spec;
+    int kernel = 0;
+    size_t itemsize = 0;
+    std::mutex stats_mu;
+    Stats stats;
+  };
+  struct Request;
+  bool Run(Request* req, const std::shared_ptr<Model>& model);
+  std::shared_ptr<Model> FindModel(const std::string& name, const std::string& version);
+
+  std::atomic<bool> enabled_{true};
+  std::atomic<uint64_t> handled_{0}, declined_{0};
+  std::shared_mutex mu_;
+  std::map<std::string, std::shared_ptr<Model>> models_;
+  std::map<std::string, std::shared_ptr<Region>> regions_;
+};
+
+}  // namespace server
+}  // namespace tca

@@ -1,0 +1,695 @@
+// Native execution path (see tca/native_executor.h).
+#include "tca/native_executor.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstring>
+
+#include "tca/json.h"
+#include "tca/pbwire.h"
+
+namespace tca {
+namespace server {
+namespace {
+
+enum Kernel { kAddSub = 1, kIdentity = 2 };
+
+size_t ItemSize(const std::string& dt) {
+  if (dt == "INT8" || dt == "UINT8" || dt == "BOOL") return 1;
+  if (dt == "INT16" || dt == "UINT16" || dt == "FP16" || dt == "BF16") return 2;
+  if (dt == "INT32" || dt == "UINT32" || dt == "FP32") return 4;
+  if (dt == "INT64" || dt == "UINT64" || dt == "FP64") return 8;
+  return 0;
+}
+
+inline uint64_t NowNs() {
+  return static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                   std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+
+// Integer arithmetic wraps like numpy's fixed-width types do.
+template <typename T, typename U>
+void AddSubT(const uint8_t* a, const uint8_t* b, uint8_t* sum, uint8_t* diff, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    T x, y;
+    std::memcpy(&x, a + i * sizeof(T), sizeof(T));
+    std::memcpy(&y, b + i * sizeof(T), sizeof(T));
+    const T s = static_cast<T>(static_cast<U>(x) + static_cast<U>(y));
+    const T d = static_cast<T>(static_cast<U>(x) - static_cast<U>(y));
+    if (sum) std::memcpy(sum + i * sizeof(T), &s, sizeof(T));
+    if (diff) std::memcpy(diff + i * sizeof(T), &d, sizeof(T));
+  }
+}
+
+bool AddSub(const std::string& dt, const uint8_t* a, const uint8_t* b, uint8_t* sum, uint8_t* diff, size_t n) {
+  if (dt == "INT32") AddSubT<int32_t, uint32_t>(a, b, sum, diff, n);
+  else if (dt == "INT8") AddSubT<int8_t, uint8_t>(a, b, sum, diff, n);
+  else if (dt == "INT16") AddSubT<int16_t, uint16_t>(a, b, sum, diff, n);
+  else if (dt == "INT64") AddSubT<int64_t, uint64_t>(a, b, sum, diff, n);
+  else if (dt == "UINT8") AddSubT<uint8_t, uint8_t>(a, b, sum, diff, n);
+  else if (dt == "UINT16") AddSubT<uint16_t, uint16_t>(a, b, sum, diff, n);
+  else if (dt == "UINT32") AddSubT<uint32_t, uint32_t>(a, b, sum, diff, n);
+  else if (dt == "UINT64") AddSubT<uint64_t, uint64_t>(a, b, sum, diff, n);
+  else if (dt == "FP32") AddSubT<float, float>(a, b, sum, diff, n);
+  else if (dt == "FP64") AddSubT<double, double>(a, b, sum, diff, n);
+  else return false;
+  return true;
+}
+
+struct ShmRef {
+  bool set = false;
+  std::string region;
+  int64_t size = 0, offset = 0;
+};
+
+}  // namespace
+
+struct NativeExecutor::Request {
+  struct Input {
+    std::string name, datatype;
+    std::vector<int64_t> shape;
+    const uint8_t* data = nullptr;  // wire bytes, or resolved shm window
+    size_t size = 0;
+    ShmRef shm;
+    bool has_data = false;
+  };
+  struct Output {
+    std::string name;
+    ShmRef shm;
+    bool binary = true;  // HTTP only
+  };
+  std::string model, version, id;
+  std::vector<Input> inputs;
+  std::vector<Output> outputs;  // empty = all
+  // results
+  struct Result {
+    std::string name, datatype;
+    std::vector<int64_t> shape;
+    std::string bytes;  // when not in shared memory
+    ShmRef shm;
+    size_t shm_bytes = 0;
+  };
+  std::vector<Result> results;
+  std::string version_used;
+  std::vector<std::shared_ptr<Region>> held;  // regions in use stay mapped until the answer is built
+  uint64_t t_arrive = 0;
+};
+
+NativeExecutor::Region::~Region() {
+  if (map != nullptr) munmap(map, map_size);
+}
+
+Error NativeExecutor::SetModel(const ModelSpec& spec) {
+  auto m = std::make_shared<Model>();
+  m->spec = spec;
+  if (spec.kernel == "add_sub") {
+    if (spec.inputs.size() != 2 || spec.outputs.size() != 2) return Error("add_sub needs two inputs and two outputs");
+    m->kernel = kAddSub;
+  } else if (spec.kernel == "identity") {
+    if (spec.inputs.size() != 1 || spec.outputs.size() != 1) return Error("identity needs one input and one output");
+    m->kernel = kIdentity;
+  } else {
+    return Error("unknown native kernel '" + spec.kernel + "'");
+  }
+  const std::string& dt = spec.inputs[0].datatype;
+  m->itemsize = ItemSize(dt);
+  if (m->itemsize == 0) return Error("datatype '" + dt + "' has no native kernel");
+  for (const auto& t : spec.inputs)
+    if (t.datatype != dt || t.dims != spec.inputs[0].dims) return Error("native kernels need equally typed and shaped tensors");
+  for (const auto& t : spec.outputs)
+    if (t.datatype != dt || t.dims != spec.inputs[0].dims) return Error("native kernels need equally typed and shaped tensors");
+  if (m->kernel == kAddSub && (dt == "BOOL" || dt == "FP16" || dt == "BF16")) return Error("add_sub has no " + dt + " form");
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  models_[spec.name] = std::move(m);
+  return Error::Success();
+}
+
+void NativeExecutor::RemoveModel(const std::string& name) {
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  models_.erase(name);
+}
+
+Error NativeExecutor::RegisterRegion(const std::string& name, const std::string& key, uint64_t offset, uint64_t size) {
+  const int fd = shm_open(key.c_str(), O_RDWR, 0);
+  if (fd < 0) return Error("unable to open shared memory object '" + key + "'");
+  struct stat st {};
+  if (fstat(fd, &st) != 0 || offset + size < offset || static_cast<uint64_t>(st.st_size) < offset + size) {
+    close(fd);
+    return Error("shared memory object '" + key + "' is smaller than offset + byte size");
+  }
+  void* p = mmap(nullptr, offset + size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return Error("unable to map shared memory object '" + key + "'");
+  auto r = std::make_shared<Region>();
+  r->map = p;
+  r->map_size = offset + size;
+  r->base = static_cast<uint8_t*>(p) + offset;
+  r->size = size;
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  regions_[name] = std::move(r);
+  return Error::Success();
+}
+
+void NativeExecutor::UnregisterRegion(const std::string& name) {
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  if (name.empty()) regions_.clear();
+  else regions_.erase(name);
+}
+
+std::shared_ptr<NativeExecutor::Model> NativeExecutor::FindModel(const std::string& name, const std::string& version) {
+  std::shared_lock<std::shared_mutex> lk(mu_);
+  auto it = models_.find(name);
+  if (it == models_.end()) return nullptr;
+  if (!version.empty() && version != it->second->spec.version) return nullptr;
+  return it->second;
+}
+
+bool NativeExecutor::TakeStats(const std::string& name, Stats* out) {
+  std::shared_ptr<Model> m;
+  {
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    auto it = models_.find(name);
+    if (it == models_.end()) return false;
+    m = it->second;
+  }
+  std::lock_guard<std::mutex> lk(m->stats_mu);
+  if (m->stats.requests == 0) return false;
+  *out = std::move(m->stats);
+  m->stats = Stats();
+  return true;
+}
+
+// Validates the decoded request against the model exactly as far as needed to be sure the general
+// path would accept it too, then runs the kernel.  False = not ours (nothing has been written).
+bool NativeExecutor::Run(Request* req, const std::shared_ptr<Model>& model) {
+  const ModelSpec& spec = model->spec;
+  const uint64_t t0 = NowNs();
+  if (req->inputs.size() != spec.inputs.size()) return false;
+  const Request::Input* ordered[2] = {nullptr, nullptr};
+  int64_t batch = 0;
+  size_t count = 0;
+  for (auto& in : req->inputs) {
+    size_t slot = spec.inputs.size();
+    for (size_t k = 0; k < spec.inputs.size(); ++k)
+      if (spec.inputs[k].name == in.name) slot = k;
+    if (slot == spec.inputs.size() || ordered[slot] != nullptr) return false;
+    const TensorSpec& ts = spec.inputs[slot];
+    if (in.datatype != ts.datatype) return false;
+    const size_t lead = spec.max_batch > 0 ? 1 : 0;
+    if (in.shape.size() != ts.dims.size() + lead) return false;
+    size_t n = 1;
+    for (size_t d = 0; d < in.shape.size(); ++d) {
+      const int64_t v = in.shape[d];
+      if (v < 0 || v > (int64_t(1) << 32)) return false;
+      if (d >= lead && ts.dims[d - lead] != -1 && ts.dims[d - lead] != v) return false;
+      n *= static_cast<size_t>(v);
+      if (n > (size_t(1) << 34)) return false;
+    }
+    if (lead) {
+      if (in.shape[0] < 1 || in.shape[0] > spec.max_batch) return false;
+      batch = in.shape[0];
+    }
+    if (ordered[0] != nullptr && in.shape != ordered[0]->shape) return false;
+    if (in.shm.set) {
+      std::shared_ptr<Region> region;
+      {
+        std::shared_lock<std::shared_mutex> lk(mu_);
+        auto it = regions_.find(in.shm.region);
+        if (it != regions_.end()) region = it->second;
+      }
+      if (!region || in.shm.offset < 0 || in.shm.size < 0 ||
+          static_cast<uint64_t>(in.shm.offset) + static_cast<uint64_t>(in.shm.size) > region->size)
+        return false;
+      in.data = region->base + in.shm.offset;
+      in.size = static_cast<size_t>(in.shm.size);
+      req->held.push_back(std::move(region));
+    } else if (!in.has_data) {
+      return false;
+    }
+    if (in.size != n * model->itemsize) return false;
+    count = n;
+    ordered[slot] = &in;
+  }
+  if (spec.inputs.size() == 2 && ordered[0]->shape != ordered[1]->shape) return false;
+  // outputs: the requested ones, or all of them
+  std::vector<Request::Output> wanted = req->outputs;
+  if (wanted.empty())
+    for (const auto& t : spec.outputs) {
+      Request::Output o;
+      o.name = t.name;
+      wanted.push_back(o);
+    }
+  const size_t nbytes = count * model->itemsize;
+  req->results.clear();
+  req->results.reserve(wanted.size());
+  std::vector<uint8_t*> dest(spec.outputs.size(), nullptr);
+  for (const auto& o : wanted) {
+    size_t slot = spec.outputs.size();
+    for (size_t k = 0; k < spec.outputs.size(); ++k)
+      if (spec.outputs[k].name == o.name) slot = k;
+    if (slot == spec.outputs.size() || dest[slot] != nullptr) return false;
+    Request::Result r;
+    r.name = o.name;
+    r.datatype = spec.outputs[slot].datatype;
+    r.shape = ordered[0]->shape;
+    if (o.shm.set) {
+      std::shared_ptr<Region> region;
+      {
+        std::shared_lock<std::shared_mutex> lk(mu_);
+        auto it = regions_.find(o.shm.region);
+        if (it != regions_.end()) region = it->second;
+      }
+      if (!region || o.shm.offset < 0 || o.shm.size < 0 || static_cast<uint64_t>(o.shm.size) < nbytes ||
+          static_cast<uint64_t>(o.shm.offset) + nbytes > region->size)
+        return false;
+      r.shm = o.shm;
+      r.shm_bytes = nbytes;
+      req->results.push_back(std::move(r));
+      dest[slot] = region->base + o.shm.offset;
+      req->held.push_back(std::move(region));
+    } else {
+      r.bytes.resize(nbytes);
+      req->results.push_back(std::move(r));
+      dest[slot] = reinterpret_cast<uint8_t*>(&req->results.back().bytes[0]);
+    }
+  }
+  // `results` does not grow any more, but the pointers into its strings were taken while it did:
+  // strings of this size live on the heap, and reserve() above keeps the vector in place
+  const uint64_t t1 = NowNs();
+  if (model->kernel == kAddSub) {
+    if (!AddSub(spec.inputs[0].datatype, ordered[0]->data, ordered[1]->data, dest[0], dest[1], count)) return false;
+  } else {
+    if (dest[0] != nullptr) std::memcpy(dest[0], ordered[0]->data, nbytes);
+  }
+  const uint64_t t2 = NowNs();
+  req->version_used = spec.version;
+  {
+    const int b = static_cast<int>(batch > 0 ? batch : 1);
+    std::lock_guard<std::mutex> lk(model->stats_mu);
+    Stats& s = model->stats;
+    ++s.requests;
+    s.inferences += static_cast<uint64_t>(b);
+    s.queue_ns += t0 - req->t_arrive;
+    s.last_ms = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::milliseconds>(
+                                          std::chrono::system_clock::now().time_since_epoch()).count());
+    BatchStats& bs = s.by_batch[b];
+    ++bs.count;
+    bs.input_ns += t1 - t0;
+    bs.infer_ns += t2 - t1;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gRPC
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// map<string, InferParameter> entry -> shm reference fields; false on a key this path does not know.
+bool ShmParam(const uint8_t* d, size_t n, ShmRef* shm, bool* other) {
+  pb::Reader e(d, n);
+  std::string key;
+  const uint8_t* vd = nullptr;
+  size_t vn = 0;
+  uint32_t f, wt;
+  while (e.Next(&f, &wt)) {
+    if (f == 1 && wt == pb::kLen) {
+      if (!e.String(&key)) return false;
+    } else if (f == 2 && wt == pb::kLen) {
+      if (!e.Len(&vd, &vn)) return false;
+    } else if (!e.Skip(wt)) {
+      return false;
+    }
+  }
+  if (e.Failed()) return false;
+  std::string sval;
+  int64_t ival = 0;
+  bool has_s = false, has_i = false;
+  pb::Reader p(vd, vn);
+  while (p.Next(&f, &wt)) {
+    uint64_t u;
+    if (f == 2 && wt == pb::kVarint) {
+      if (!p.Varint(&u)) return false;
+      ival = static_cast<int64_t>(u);
+      has_i = true;
+    } else if (f == 3 && wt == pb::kLen) {
+      if (!p.String(&sval)) return false;
+      has_s = true;
+    } else {
+      *other = true;
+      if (!p.Skip(wt)) return false;
+    }
+  }
+  if (p.Failed()) return false;
+  if (key == "shared_memory_region" && has_s) {
+    shm->set = true;
+    shm->region = sval;
+  } else if (key == "shared_memory_byte_size" && has_i) {
+    shm->size = ival;
+  } else if (key == "shared_memory_offset" && has_i) {
+    shm->offset = ival;
+  } else {
+    *other = true;
+  }
+  return true;
+}
+
+}  // namespace
+
+bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) {
+  if (!enabled_.load(std::memory_order_relaxed)) return false;
+  Request req;
+  req.t_arrive = NowNs();
+  std::vector<std::pair<const uint8_t*, size_t>> raws;
+  pb::Reader r(request);
+  uint32_t f, wt;
+  bool other = false;
+  while (r.Next(&f, &wt)) {
+    if (f == 1 && wt == pb::kLen) {
+      if (!r.String(&req.model)) return false;
+      // cheap early out: most servers hold many models without a native kernel
+      if (!FindModel(req.model, std::string())) return false;
+    } else if (f == 2 && wt == pb::kLen) {
+      if (!r.String(&req.version)) return false;
+    } else if (f == 3 && wt == pb::kLen) {
+      if (!r.String(&req.id)) return false;
+    } else if (f == 4) {
+      return false;  // request parameters (sequences, priorities, timeouts...): general path
+    } else if (f == 5 && wt == pb::kLen) {
+      const uint8_t* d;
+      size_t n;
+      if (!r.Len(&d, &n)) return false;
+      Request::Input in;
+      pb::Reader t(d, n);
+      uint32_t tf, twt;
+      while (t.Next(&tf, &twt)) {
+        if (tf == 1 && twt == pb::kLen) {
+          if (!t.String(&in.name)) return false;
+        } else if (tf == 2 && twt == pb::kLen) {
+          if (!t.String(&in.datatype)) return false;
+        } else if (tf == 3 && twt == pb::kLen) {  // packed int64
+          const uint8_t* sd;
+          size_t sn;
+          if (!t.Len(&sd, &sn)) return false;
+          pb::Reader s(sd, sn);
+          while (!s.Done()) {
+            uint64_t v;
+            if (!s.Varint(&v)) return false;
+            in.shape.push_back(static_cast<int64_t>(v));
+          }
+        } else if (tf == 3 && twt == pb::kVarint) {
+          uint64_t v;
+          if (!t.Varint(&v)) return false;
+          in.shape.push_back(static_cast<int64_t>(v));
+        } else if (tf == 4 && twt == pb::kLen) {
+          const uint8_t* pd;
+          size_t pn;
+          if (!t.Len(&pd, &pn) || !ShmParam(pd, pn, &in.shm, &other)) return false;
+        } else {
+          return false;  // typed contents and anything newer: general path
+        }
+      }
+      if (t.Failed() || other) return false;
+      req.inputs.push_back(std::move(in));
+    } else if (f == 6 && wt == pb::kLen) {
+      const uint8_t* d;
+      size_t n;
+      if (!r.Len(&d, &n)) return false;
+      Request::Output out;
+      pb::Reader t(d, n);
+      uint32_t tf, twt;
+      while (t.Next(&tf, &twt)) {
+        if (tf == 1 && twt == pb::kLen) {
+          if (!t.String(&out.name)) return false;
+        } else if (tf == 2 && twt == pb::kLen) {
+          const uint8_t* pd;
+          size_t pn;
+          if (!t.Len(&pd, &pn) || !ShmParam(pd, pn, &out.shm, &other)) return false;
+        } else {
+          return false;
+        }
+      }
+      if (t.Failed() || other) return false;
+      req.outputs.push_back(std::move(out));
+    } else if (f == 7 && wt == pb::kLen) {
+      const uint8_t* d;
+      size_t n;
+      if (!r.Len(&d, &n)) return false;
+      raws.emplace_back(d, n);
+    } else {
+      return false;
+    }
+  }
+  if (r.Failed() || req.model.empty()) return false;
+  std::shared_ptr<Model> model = FindModel(req.model, req.version);
+  if (!model) return false;
+  // raw contents belong to the inputs that are not in shared memory, in order
+  size_t next_raw = 0;
+  for (auto& in : req.inputs) {
+    if (in.shm.set) continue;
+    if (next_raw >= raws.size()) return false;
+    in.data = raws[next_raw].first;
+    in.size = raws[next_raw].second;
+    in.has_data = true;
+    ++next_raw;
+  }
+  if (next_raw != raws.size()) return false;
+  if (!Run(&req, model)) {
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return false;
+  }
+  const uint64_t t2 = NowNs();
+  response->clear();
+  response->reserve(256);
+  pb::Writer w(response);
+  w.String(1, req.model);
+  w.String(2, req.version_used);
+  if (!req.id.empty()) w.String(3, req.id);
+  std::string scratch, entry, value;
+  for (const auto& res : req.results) {
+    scratch.clear();
+    pb::Writer t(&scratch);
+    t.String(1, res.name);
+    t.String(2, res.datatype);
+    size_t packed = 0;
+    for (int64_t v : res.shape) packed += pb::Writer::VarintSize(static_cast<uint64_t>(v));
+    t.LenHeader(3, packed);
+    for (int64_t v : res.shape) t.Varint(static_cast<uint64_t>(v));
+    if (res.shm.set) {
+      auto param = [&](const char* key, const std::string* s, int64_t i) {
+        entry.clear();
+        value.clear();
+        pb::Writer ew(&entry), vw(&value);
+        if (s != nullptr) vw.String(3, *s);
+        else vw.Int(2, i);
+        ew.String(1, key);
+        ew.Message(2, value);
+        t.Message(4, entry);
+      };
+      param("shared_memory_region", &res.shm.region, 0);
+      param("shared_memory_byte_size", nullptr, res.shm.size);
+      if (res.shm.offset) param("shared_memory_offset", nullptr, res.shm.offset);
+    }
+    w.Message(5, scratch);
+  }
+  for (const auto& res : req.results)
+    if (!res.shm.set) w.Bytes(6, res.bytes.data(), res.bytes.size());
+  {
+    int batch = 1;
+    if (model->spec.max_batch > 0 && !req.results.empty() && !req.results[0].shape.empty())
+      batch = static_cast<int>(req.results[0].shape[0]);
+    std::lock_guard<std::mutex> lk(model->stats_mu);
+    model->stats.by_batch[batch].output_ns += NowNs() - t2;
+  }
+  handled_.fetch_add(1, std::memory_order_relaxed);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HTTP
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// "parameters" object of an input / output; false when it holds a key this path does not know.
+bool HttpParams(const json::Value* params, ShmRef* shm, int64_t* binary_size, bool* has_binary_size, bool* binary_flag,
+                bool* has_binary_flag) {
+  if (params == nullptr) return true;
+  if (!params->IsObject()) return false;
+  for (const auto& kv : params->Members()) {
+    const std::string& k = kv.first;
+    const json::Value& v = kv.second;
+    if (k == "shared_memory_region" && v.IsString()) {
+      shm->set = true;
+      shm->region = v.AsString();
+    } else if (k == "shared_memory_byte_size" && v.IsNumber()) {
+      shm->size = v.AsInt();
+    } else if (k == "shared_memory_offset" && v.IsNumber()) {
+      shm->offset = v.AsInt();
+    } else if (k == "binary_data_size" && v.IsNumber() && binary_size != nullptr) {
+      *binary_size = v.AsInt();
+      *has_binary_size = true;
+    } else if (k == "binary_data" && v.IsBool() && binary_flag != nullptr) {
+      *binary_flag = v.AsBool();
+      *has_binary_flag = true;
+    } else {
+      return false;
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& version, const std::string& body,
+                             int64_t header_length, HeaderList* headers, std::vector<std::string>* parts) {
+  if (!enabled_.load(std::memory_order_relaxed)) return false;
+  std::shared_ptr<Model> model = FindModel(model_name, version);
+  if (!model) return false;
+  Request req;
+  req.t_arrive = NowNs();
+  req.model = model_name;
+  req.version = version;
+  size_t json_len = body.size();
+  if (header_length >= 0) {
+    if (static_cast<uint64_t>(header_length) > body.size()) return false;
+    json_len = static_cast<size_t>(header_length);
+  }
+  json::Value doc;
+  if (!json::Parse(body.data(), json_len, &doc).IsOk() || !doc.IsObject()) return false;
+  bool default_binary = false;
+  const json::Value* inputs = nullptr;
+  const json::Value* outputs = nullptr;
+  for (const auto& kv : doc.Members()) {
+    if (kv.first == "id" && kv.second.IsString()) {
+      req.id = kv.second.AsString();
+    } else if (kv.first == "inputs" && kv.second.IsArray()) {
+      inputs = &kv.second;
+    } else if (kv.first == "outputs" && kv.second.IsArray()) {
+      outputs = &kv.second;
+    } else if (kv.first == "parameters" && kv.second.IsObject()) {
+      for (const auto& p : kv.second.Members()) {
+        if (p.first == "binary_data_output" && p.second.IsBool()) default_binary = p.second.AsBool();
+        else return false;
+      }
+    } else {
+      return false;
+    }
+  }
+  if (inputs == nullptr) return false;
+  size_t cursor = json_len;
+  for (const auto& item : inputs->Items()) {
+    if (!item.IsObject()) return false;
+    Request::Input in;
+    const json::Value* params = nullptr;
+    for (const auto& kv : item.Members()) {
+      if (kv.first == "name" && kv.second.IsString()) in.name = kv.second.AsString();
+      else if (kv.first == "datatype" && kv.second.IsString()) in.datatype = kv.second.AsString();
+      else if (kv.first == "shape" && kv.second.IsArray()) {
+        for (const auto& d : kv.second.Items()) {
+          if (!d.IsNumber()) return false;
+          in.shape.push_back(d.AsInt());
+        }
+      } else if (kv.first == "parameters") params = &kv.second;
+      else return false;  // "data" in JSON form and anything else: general path
+    }
+    int64_t bsize = 0;
+    bool has_bsize = false;
+    if (!HttpParams(params, &in.shm, &bsize, &has_bsize, nullptr, nullptr)) return false;
+    if (!in.shm.set) {
+      if (!has_bsize || bsize < 0 || cursor + static_cast<uint64_t>(bsize) > body.size()) return false;
+      in.data = reinterpret_cast<const uint8_t*>(body.data()) + cursor;
+      in.size = static_cast<size_t>(bsize);
+      in.has_data = true;
+      cursor += static_cast<size_t>(bsize);
+    } else if (has_bsize) {
+      return false;
+    }
+    req.inputs.push_back(std::move(in));
+  }
+  if (cursor != body.size()) return false;
+  if (outputs != nullptr) {
+    for (const auto& item : outputs->Items()) {
+      if (!item.IsObject()) return false;
+      Request::Output out;
+      out.binary = default_binary;
+      const json::Value* params = nullptr;
+      for (const auto& kv : item.Members()) {
+        if (kv.first == "name" && kv.second.IsString()) out.name = kv.second.AsString();
+        else if (kv.first == "parameters") params = &kv.second;
+        else return false;
+      }
+      bool flag = false, has_flag = false;
+      if (!HttpParams(params, &out.shm, nullptr, nullptr, &flag, &has_flag)) return false;
+      if (has_flag) out.binary = flag;
+      if (!out.shm.set && !out.binary) return false;  // JSON "data" answers: general path
+      req.outputs.push_back(std::move(out));
+    }
+  } else if (!default_binary) {
+    return false;
+  }
+  if (!Run(&req, model)) {
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return false;
+  }
+  const uint64_t t2 = NowNs();
+  std::string head;
+  head.reserve(384);
+  head += "{\"model_name\":";
+  json::detail::WriteEscaped(req.model, &head);
+  head += ",\"model_version\":";
+  json::detail::WriteEscaped(req.version_used, &head);
+  if (!req.id.empty()) {
+    head += ",\"id\":";
+    json::detail::WriteEscaped(req.id, &head);
+  }
+  head += ",\"outputs\":[";
+  bool first = true, any_blob = false;
+  for (const auto& res : req.results) {
+    if (!first) head += ',';
+    first = false;
+    head += "{\"name\":";
+    json::detail::WriteEscaped(res.name, &head);
+    head += ",\"datatype\":\"" + res.datatype + "\",\"shape\":[";
+    for (size_t i = 0; i < res.shape.size(); ++i) {
+      if (i) head += ',';
+      head += std::to_string(res.shape[i]);
+    }
+    head += "],\"parameters\":{";
+    if (res.shm.set) {
+      head += "\"shared_memory_region\":";
+      json::detail::WriteEscaped(res.shm.region, &head);
+      head += ",\"shared_memory_byte_size\":" + std::to_string(res.shm.size);
+      if (res.shm.offset) head += ",\"shared_memory_offset\":" + std::to_string(res.shm.offset);
+    } else {
+      head += "\"binary_data_size\":" + std::to_string(res.bytes.size());
+      any_blob = true;
+    }
+    head += "}}";
+  }
+  head += "]}";
+  headers->clear();
+  parts->clear();
+  if (any_blob) {
+    headers->emplace_back("Inference-Header-Content-Length", std::to_string(head.size()));
+    headers->emplace_back("Content-Type", "application/octet-stream");
+  }
+  parts->push_back(std::move(head));
+  for (auto& res : req.results)
+    if (!res.shm.set) parts->push_back(std::move(res.bytes));
+  {
+    int batch = 1;
+    if (model->spec.max_batch > 0 && !req.results.empty() && !req.results[0].shape.empty())
+      batch = static_cast<int>(req.results[0].shape[0]);
+    std::lock_guard<std::mutex> lk(model->stats_mu);
+    model->stats.by_batch[batch].output_ns += NowNs() - t2;
+  }
+  handled_.fetch_add(1, std::memory_order_relaxed);
+  return true;
+}
+
+}  // namespace server
+}  // namespace tca

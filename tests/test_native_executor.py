@@ -1,0 +1,207 @@
+"""Native execution path: ordinary requests for models with a C++ kernel are answered by the
+serving fronts without the interpreter; everything else takes the general path.  Both must be
+indistinguishable to a client, so every case runs against a server with the path on and one
+with it off and the answers are compared."""
+import numpy as np
+import pytest
+
+import tritonclient.grpc as grpcclient
+import tritonclient.http as httpclient
+import tritonclient.utils.shared_memory as shm
+from tritonclient.utils import InferenceServerException
+
+
+@pytest.fixture(scope="module")
+def servers():
+    from triton_client_amd.server import Server
+
+    models = ["simple", "simple_int8", "simple_string", "custom_identity_int32"]
+    on = Server(models=models, native_exec=True, model_control="explicit").start()
+    off = Server(models=models, native_exec=False, model_control="explicit").start()
+    for srv in (on, off):
+        with httpclient.InferenceServerClient(srv.http_url) as c:
+            for m in models:
+                c.load_model(m)
+    if on._native is None:
+        on.stop()
+        off.stop()
+        pytest.skip("native extension not built")
+    yield on, off
+    on.stop()
+    off.stop()
+
+
+def _handled(srv):
+    return srv._native.counters()["handled"]
+
+
+def _inputs(mod, a, b, dtype="INT32", **kw):
+    return [mod.InferInput("INPUT0", list(a.shape), dtype).set_data_from_numpy(a, **kw),
+            mod.InferInput("INPUT1", list(b.shape), dtype).set_data_from_numpy(b, **kw)]
+
+
+@pytest.mark.parametrize("batch", [1, 3, 8])
+def test_grpc_wire_requests_run_natively_and_match(servers, batch):
+    on, off = servers
+    rng = np.random.default_rng(batch)
+    a = rng.integers(-2**31, 2**31 - 1, size=(batch, 16), dtype=np.int64).astype(np.int32)  # wrap-around included
+    b = rng.integers(-2**31, 2**31 - 1, size=(batch, 16), dtype=np.int64).astype(np.int32)
+    before = _handled(on)
+    answers = []
+    for srv in (on, off):
+        with grpcclient.InferenceServerClient(srv.grpc_url) as c:
+            r = c.infer("simple", _inputs(grpcclient, a, b), request_id="abc")
+            only1 = c.infer("simple", _inputs(grpcclient, a, b), outputs=[grpcclient.InferRequestedOutput("OUTPUT1")])
+            answers.append((r.as_numpy("OUTPUT0"), r.as_numpy("OUTPUT1"), r.get_response().id,
+                            r.get_response().model_version, [o.name for o in only1.get_response().outputs],
+                            only1.as_numpy("OUTPUT1")))
+    assert _handled(on) == before + 2
+    for x, y in zip(*answers):
+        if isinstance(x, np.ndarray):
+            np.testing.assert_array_equal(x, y)
+        else:
+            assert x == y
+    with np.errstate(over="ignore"):
+        np.testing.assert_array_equal(answers[0][0], a + b)
+        np.testing.assert_array_equal(answers[0][1], a - b)
+
+
+def test_int8_kernel_and_identity_fall_back_cleanly(servers):
+    on, off = servers
+    a = np.arange(-8, 8, dtype=np.int8).reshape(1, 16) * 15
+    b = np.full((1, 16), 100, dtype=np.int8)
+    before = _handled(on)
+    outs = []
+    for srv in (on, off):
+        with grpcclient.InferenceServerClient(srv.grpc_url) as c:
+            r = c.infer("simple_int8", _inputs(grpcclient, a, b, "INT8"))
+            outs.append((r.as_numpy("OUTPUT0"), r.as_numpy("OUTPUT1")))
+            x = np.arange(32, dtype=np.int32).reshape(1, 32)
+            inp = grpcclient.InferInput("INPUT0", [1, 32], "INT32").set_data_from_numpy(x)
+            np.testing.assert_array_equal(c.infer("custom_identity_int32", [inp]).as_numpy("OUTPUT0"), x)
+    assert _handled(on) == before + 1  # the model without a kernel went to Python
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("binary_in,binary_out", [(True, True), (True, False), (False, True)])
+def test_http_requests_match(servers, binary_in, binary_out):
+    on, off = servers
+    a = np.arange(32, dtype=np.int32).reshape(2, 16)
+    b = np.full((2, 16), 7, dtype=np.int32)
+    before = _handled(on)
+    docs = []
+    for srv in (on, off):
+        with httpclient.InferenceServerClient(srv.http_url) as c:
+            outputs = [httpclient.InferRequestedOutput("OUTPUT0", binary_data=binary_out),
+                       httpclient.InferRequestedOutput("OUTPUT1", binary_data=binary_out)]
+            r = c.infer("simple", _inputs(httpclient, a, b, binary_data=binary_in), outputs=outputs, request_id="r1")
+            np.testing.assert_array_equal(r.as_numpy("OUTPUT0"), a + b)
+            np.testing.assert_array_equal(r.as_numpy("OUTPUT1"), a - b)
+            docs.append(r.get_response())
+    assert docs[0] == docs[1]
+    # only fully binary exchanges have a native form; JSON tensors go through Python
+    assert _handled(on) == before + (1 if binary_in and binary_out else 0)
+
+
+@pytest.mark.parametrize("protocol", ["http", "grpc"])
+def test_system_shared_memory_requests_match(servers, protocol):
+    on, off = servers
+    mod = httpclient if protocol == "http" else grpcclient
+    a = np.arange(16, dtype=np.int32).reshape(1, 16)
+    b = np.full((1, 16), 5, dtype=np.int32)
+    for tag, srv in (("on", on), ("off", off)):
+        key_in, key_out = f"/ne_in_{protocol}_{tag}", f"/ne_out_{protocol}_{tag}"
+        h_in = shm.create_shared_memory_region("ne_in", key_in, 128)
+        h_out = shm.create_shared_memory_region("ne_out", key_out, 128)
+        before = _handled(on)
+        try:
+            shm.set_shared_memory_region(h_in, [a, b])
+            with mod.InferenceServerClient(srv.http_url if protocol == "http" else srv.grpc_url) as c:
+                c.register_system_shared_memory("ne_in", key_in, 128)
+                c.register_system_shared_memory("ne_out", key_out, 128)
+                i0 = mod.InferInput("INPUT0", [1, 16], "INT32").set_shared_memory("ne_in", 64)
+                i1 = mod.InferInput("INPUT1", [1, 16], "INT32").set_shared_memory("ne_in", 64, offset=64)
+                o0 = mod.InferRequestedOutput("OUTPUT0")
+                o0.set_shared_memory("ne_out", 64)
+                o1 = mod.InferRequestedOutput("OUTPUT1")
+                o1.set_shared_memory("ne_out", 64, offset=64)
+                r = c.infer("simple", [i0, i1], outputs=[o0, o1])
+                out0 = r.get_output("OUTPUT0")
+                params = out0["parameters"] if isinstance(out0, dict) else {k: (v.string_param or v.int64_param)
+                                                                              for k, v in out0.parameters.items()}
+                assert params["shared_memory_region"] == "ne_out" and int(params["shared_memory_byte_size"]) == 64
+                np.testing.assert_array_equal(shm.get_contents_as_numpy(h_out, np.int32, [1, 16]), a + b)
+                np.testing.assert_array_equal(shm.get_contents_as_numpy(h_out, np.int32, [1, 16], offset=64), a - b)
+                # an output window that is too small is an error from the general path, natively declined
+                o_small = mod.InferRequestedOutput("OUTPUT0")
+                o_small.set_shared_memory("ne_out", 32)
+                with pytest.raises(InferenceServerException, match="should be at least 64 bytes"):
+                    c.infer("simple", [i0, i1], outputs=[o_small])
+                c.unregister_system_shared_memory("ne_in")
+                with pytest.raises(InferenceServerException, match="Unable to find"):
+                    c.infer("simple", [i0, i1], outputs=[o0, o1])
+                c.unregister_system_shared_memory("ne_out")
+            if tag == "on":
+                assert _handled(on) == before + 1
+        finally:
+            shm.destroy_shared_memory_region(h_in)
+            shm.destroy_shared_memory_region(h_out)
+
+
+def test_errors_and_special_requests_take_the_general_path(servers):
+    on, off = servers
+    a = np.arange(16, dtype=np.int32).reshape(1, 16)
+    b = np.ones((1, 16), dtype=np.int32)
+    before = _handled(on)
+    for srv in (on, off):
+        with grpcclient.InferenceServerClient(srv.grpc_url) as c:
+            with pytest.raises(InferenceServerException, match="unexpected shape"):
+                bad = np.zeros((1, 15), dtype=np.int32)
+                c.infer("simple", _inputs(grpcclient, bad, bad))
+            with pytest.raises(InferenceServerException, match="batch-size must be <= 8"):
+                big = np.zeros((9, 16), dtype=np.int32)
+                c.infer("simple", _inputs(grpcclient, big, big))
+            with pytest.raises(InferenceServerException, match="data-type"):
+                f = np.zeros((1, 16), dtype=np.float32)
+                c.infer("simple", _inputs(grpcclient, f, f, "FP32"))
+            with pytest.raises(InferenceServerException, match="unexpected inference output"):
+                c.infer("simple", _inputs(grpcclient, a, b), outputs=[grpcclient.InferRequestedOutput("NOPE")])
+            with pytest.raises(InferenceServerException, match="version 7 is not found"):
+                c.infer("simple", _inputs(grpcclient, a, b), model_version="7")
+            # request parameters, classification and a compressed request: answered, by Python
+            r = c.infer("simple", _inputs(grpcclient, a, b), parameters={"note": "x"})
+            np.testing.assert_array_equal(r.as_numpy("OUTPUT0"), a + b)
+            r = c.infer("simple", _inputs(grpcclient, a, b), outputs=[grpcclient.InferRequestedOutput("OUTPUT0", class_count=2)])
+            assert r.as_numpy("OUTPUT0").shape == (1, 2)
+            r = c.infer("simple", _inputs(grpcclient, a, b), model_version="1")  # the current version: native again
+            np.testing.assert_array_equal(r.as_numpy("OUTPUT1"), a - b)
+    assert _handled(on) == before + 1
+
+
+def test_statistics_count_native_requests_and_unload_stops_the_path(servers):
+    on, off = servers
+    a = np.arange(32, dtype=np.int32).reshape(2, 16)
+    b = np.ones((2, 16), dtype=np.int32)
+    with grpcclient.InferenceServerClient(on.grpc_url) as c:
+        s0 = c.get_inference_statistics("simple").model_stats[0]
+        for _ in range(5):
+            c.infer("simple", _inputs(grpcclient, a, b))
+        s1 = c.get_inference_statistics("simple").model_stats[0]
+        assert s1.inference_count - s0.inference_count == 10 and s1.execution_count - s0.execution_count == 5
+        assert s1.inference_stats.success.count - s0.inference_stats.success.count == 5
+        assert s1.inference_stats.success.ns > s0.inference_stats.success.ns
+        assert any(bs.batch_size == 2 and bs.compute_infer.count >= 5 for bs in s1.batch_stats)
+        before = _handled(on)
+        c.unload_model("simple")
+        with pytest.raises(InferenceServerException, match="unknown model"):
+            c.infer("simple", _inputs(grpcclient, a, b))
+        c.load_model("simple")
+        np.testing.assert_array_equal(c.infer("simple", _inputs(grpcclient, a, b)).as_numpy("OUTPUT0"), a + b)
+        assert _handled(on) == before + 1
+        # a load with fault-injection parameters must leave the native path
+        c.load_model("simple", config='{"parameters": {"execute_delay_ms": {"string_value": "1"}}}')
+        before = _handled(on)
+        np.testing.assert_array_equal(c.infer("simple", _inputs(grpcclient, a, b)).as_numpy("OUTPUT0"), a + b)
+        assert _handled(on) == before
+        c.load_model("simple")

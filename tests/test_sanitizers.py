@@ -13,7 +13,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TARGETS = ("stress_test", "cc_unit_test", "grpc_client_test", "grpc_front_stress", "http_front_stress")
+TARGETS = ("stress_test", "cc_unit_test", "grpc_client_test", "grpc_front_stress", "http_front_stress",
+           "native_executor_test")
 
 
 def _build(kind, san):
@@ -48,3 +49,5 @@ def test_native_clients_under_sanitizer(server, kind, san, env):
     assert "PASS : front stress" in r.stdout
     r = run([os.path.join(bins, "http_front_stress"), "-n", "6", "-r", "6"])
     assert "PASS : http front stress" in r.stdout
+    r = run([os.path.join(bins, "native_executor_test")])
+    assert "PASS : native executor" in r.stdout

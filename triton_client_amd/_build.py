@@ -72,6 +72,7 @@ def build_pyext(force=False):
     suffix = sysconfig.get_config_var("EXT_SUFFIX")
     out = LIBDIR / f"_tca_pyext{suffix}"
     srcs = [CSRC / "capi" / "pyext.cc", CSRC / "capi" / "py_grpc_front.cc", CSRC / "capi" / "py_http_front.cc",
+            CSRC / "capi" / "py_native_executor.cc", CSRC / "server" / "native_executor.cc",
             CSRC / "grpc" / "grpc_server.cc", CSRC / "http" / "http_server.cc",
             CSRC / "grpc" / "grpc_compress.cc", CSRC / "h2" / "hpack.cc", CSRC / "h2" / "connection.cc",
             CSRC / "net" / "tls.cc"]

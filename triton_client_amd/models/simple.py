@@ -35,6 +35,7 @@ def _np_bytes(values, shape):
 class Simple(Model):
     name = "simple"
     inline = True  # microseconds of host work: transports may run it on their own thread
+    native_kernel = "add_sub"  # the fronts run ordinary requests in C++ (tca/native_executor.h)
     max_batch_size = 8
     inputs = [TensorSpec("INPUT0", "INT32", [16]), TensorSpec("INPUT1", "INT32", [16])]
     outputs = [TensorSpec("OUTPUT0", "INT32", [16]), TensorSpec("OUTPUT1", "INT32", [16])]
@@ -51,6 +52,7 @@ class SimpleInt8(Model):
 
     name = "simple_int8"
     inline = True  # microseconds of host work: transports may run it on their own thread
+    native_kernel = "add_sub"
     max_batch_size = 8
     inputs = [TensorSpec("INPUT0", "INT8", [16]), TensorSpec("INPUT1", "INT8", [16])]
     outputs = [TensorSpec("OUTPUT0", "INT8", [16]), TensorSpec("OUTPUT1", "INT8", [16])]

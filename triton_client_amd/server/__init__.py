@@ -30,7 +30,7 @@ class Server:
     def __init__(self, models=None, gpu=None, http_port=0, grpc_port=0, host="127.0.0.1", model_control="none",
                  enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32, grpc_impl=None,
                  tls_cert=None, tls_key=None, tls_client_ca=None, grpc_reactors=None, http_impl=None,
-                 http_reactors=None):
+                 http_reactors=None, native_exec=None):
         self.core = InferenceCore(models=models, gpu=gpu, model_control=model_control)
         self.host = host
         self._http_port = http_port
@@ -51,6 +51,19 @@ class Server:
         self._tls = (tls_cert, tls_key, tls_client_ca) if tls_cert and tls_key else None
         # epoll reactor threads of the native gRPC front (each owns the connections it accepted)
         self._grpc_reactors = int(grpc_reactors or os.environ.get("TCA_GRPC_REACTORS") or 2)
+        # requests for models with a C++ kernel are answered by the native fronts without the
+        # interpreter (tca/native_executor.h); TCA_NATIVE_EXEC=0 / native_exec=False turns that off
+        if native_exec is None:
+            native_exec = os.environ.get("TCA_NATIVE_EXEC", "1") != "0"
+        self._native = None
+        if native_exec:
+            try:
+                from .._native import pyext
+
+                self._native = pyext().NativeExecutor()
+                self.core.attach_native(self._native)
+            except Exception:  # noqa: BLE001 - extension not built: everything takes the general path
+                self._native = None
         self._loop = None
         self._thread = None
         self.http = None
@@ -70,7 +83,7 @@ class Server:
                 from .native_grpc_front import NativeGrpcFront
 
                 self.grpc = NativeGrpcFront(self.core, self.host, self._grpc_port, workers=self._grpc_workers,
-                                            reactors=self._grpc_reactors, tls=self._tls)
+                                            reactors=self._grpc_reactors, tls=self._tls, native=self._native)
             elif self._grpc_impl == "grpcio":
                 from .grpc_front import GrpcFront
 
@@ -82,7 +95,7 @@ class Server:
             from .native_http_front import NativeHttpFront
 
             self.http = NativeHttpFront(self.core, self.host, self._http_port, workers=self._http_workers,
-                                        reactors=self._http_reactors, tls=self._tls)
+                                        reactors=self._http_reactors, tls=self._tls, native=self._native)
             self._http_port = self.http.start()
         elif self._enable_http:
             if self._http_impl != "asyncio":

@@ -178,6 +178,26 @@ class ModelStats:
         with self.lock:
             self.d["fail"].add(ns)
 
+    def merge_native(self, taken):
+        """Adds what the native execution path counted since the last merge (``take_stats``)."""
+        with self.lock:
+            self.last_inference = max(self.last_inference, int(taken["last_ms"]))
+            self.inference_count += int(taken["inferences"])
+            self.execution_count += int(taken["requests"])
+            self.d["queue"].add(taken["queue_ns"], taken["requests"])
+            total = int(taken["queue_ns"])
+            for batch, (count, in_ns, infer_ns, out_ns) in taken["by_batch"].items():
+                total += in_ns + infer_ns + out_ns
+                self.d["compute_input"].add(in_ns, count)
+                self.d["compute_infer"].add(infer_ns, count)
+                self.d["compute_output"].add(out_ns, count)
+                b = self.batch.setdefault(max(1, batch), {k: _Duration() for k in
+                                                           ("compute_input", "compute_infer", "compute_output")})
+                b["compute_input"].add(in_ns, count)
+                b["compute_infer"].add(infer_ns, count)
+                b["compute_output"].add(out_ns, count)
+            self.d["success"].add(total, taken["requests"])
+
     def as_dict(self, name, version):
         with self.lock:
             return {
@@ -273,6 +293,8 @@ class _SystemRegion:
 
 
 class SystemShmRegistry(_Leased):
+    native = None  # NativeExecutor that mirrors the registrations (its own mapping of every region)
+
     def register(self, name, key, offset, byte_size):
         if int(offset) < 0 or int(byte_size) < 0:
             raise ServerError(f"Unable to open shared memory region: '{key}': negative offset or byte size", 400)
@@ -284,8 +306,15 @@ class SystemShmRegistry(_Leased):
             except sysshm.SharedMemoryException as e:
                 raise ServerError(f"Unable to open shared memory region: '{key}': {e}", 400) from None
             self._regions[name] = _SystemRegion(key, offset, byte_size, handle)
+        if self.native is not None:
+            try:
+                self.native.register_region(name, key if key.startswith("/") else "/" + key, int(offset), int(byte_size))
+            except ValueError:
+                pass  # requests naming this region take the general path
 
     def unregister(self, name=""):
+        if self.native is not None:
+            self.native.unregister_region(name or "")  # first: no request may start on a region that is going away
         with self._lock:
             removed, busy = self._drain(name)
         for _, entry in removed:
@@ -570,6 +599,7 @@ class InferenceCore:
         self._failed: Dict[str, str] = {}
         self.sysshm = SystemShmRegistry()
         self.devshm = DeviceShmRegistry()
+        self.native = None  # NativeExecutor once attach_native() has run
         self.trace_global = {
             "trace_file": [""], "trace_level": ["OFF"], "trace_rate": ["1000"], "trace_count": ["-1"],
             "log_frequency": ["0"], "trace_mode": ["triton"],
@@ -588,6 +618,52 @@ class InferenceCore:
                     self.load_model(name)
                 except ServerError as e:
                     self._failed[name] = e.message
+
+    # ------------------------------------------------------ native execution
+    def attach_native(self, executor):
+        """Hands models with a C++ kernel (``native_kernel`` on the model class) and the system
+        shared-memory registrations to ``executor``; the fronts then answer ordinary requests for
+        those models without the interpreter.  Model load / unload and region registration keep
+        it in step from here on."""
+        self.native = executor
+        self.sysshm.native = executor
+        for entry in self.sysshm.status():
+            try:
+                key = entry["key"]
+                executor.register_region(entry["name"], key if key.startswith("/") else "/" + key,
+                                         int(entry["offset"]), int(entry["byte_size"]))
+            except ValueError:
+                pass
+        with self._lock:
+            loaded = list(self._loaded.values())
+        for lm in loaded:
+            self._sync_native(lm)
+
+    def _sync_native(self, lm, present=True):
+        executor = getattr(self, "native", None)
+        if executor is None:
+            return
+        model = lm.model
+        kernel = getattr(model, "native_kernel", None)
+        eligible = present and kernel and getattr(model, "inline", False) and model.device == "cpu" \
+            and not model.parameters and not model.decoupled
+        if not eligible:
+            executor.remove_model(model.name)
+            return
+        try:
+            executor.set_model(model.name, model.versions[-1], int(model.max_batch_size),
+                               [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.inputs],
+                               [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.outputs], kernel)
+        except ValueError:
+            executor.remove_model(model.name)
+
+    def _merge_native_stats(self, name, lm):
+        executor = getattr(self, "native", None)
+        if executor is None:
+            return
+        taken = executor.take_stats(name)
+        if taken:
+            lm.stats[lm.model.versions[-1]].merge_native(taken)
 
     # ----------------------------------------------------------- repository
     def repository_index(self, ready_only=False):
@@ -638,6 +714,7 @@ class InferenceCore:
             old = self._loaded.get(name)
             self._loaded[name] = lm
             self._failed.pop(name, None)
+        self._sync_native(lm)
         if old is not None:
             self._retire(old)
 
@@ -658,6 +735,7 @@ class InferenceCore:
         if lm is None and name not in self._available:
             raise ServerError(f"failed to unload '{name}', model is not found", 400)
         if lm is not None:
+            self._sync_native(lm, present=False)
             self._retire(lm)
 
     def _get(self, name, version="") -> LoadedModel:
@@ -700,6 +778,7 @@ class InferenceCore:
             lm = self._get(name, version)
             items = [(name, lm)]
         for n, lm in items:
+            self._merge_native_stats(n, lm)
             for v, st in lm.stats.items():
                 if version and v != version:
                     continue

@@ -58,7 +58,7 @@ class _Stream:
 
 
 class NativeGrpcFront:
-    def __init__(self, core, host="127.0.0.1", port=8001, workers=16, reactors=2, tls=None):
+    def __init__(self, core, host="127.0.0.1", port=8001, workers=16, reactors=2, tls=None, native=None):
         from .._native import pyext
 
         self.core = core
@@ -89,6 +89,8 @@ class NativeGrpcFront:
         kwargs = {}
         if tls:  # (certificate chain, private key, client CA or None) as PEM file paths
             kwargs = {"tls_cert": tls[0], "tls_key": tls[1], "tls_client_ca": tls[2]}
+        if native is not None:  # NativeExecutor: ordinary requests for its models never reach on_unary
+            kwargs["native"] = native
         self._front = pyext().GrpcFront(host, int(port), int(reactors), on_unary, self._on_stream_message,
                                         self._on_stream_end, self._on_cancel, **kwargs)
 

@@ -24,7 +24,7 @@ from .http_front import Router, _dumps
 
 
 class NativeHttpFront:
-    def __init__(self, core, host="127.0.0.1", port=8000, workers=16, reactors=2, tls=None):
+    def __init__(self, core, host="127.0.0.1", port=8000, workers=16, reactors=2, tls=None, native=None):
         from .._native import pyext
 
         self.core = core
@@ -35,6 +35,8 @@ class NativeHttpFront:
         kwargs = {}
         if tls:  # (certificate chain, private key, client CA or None) as PEM file paths
             kwargs = {"tls_cert": tls[0], "tls_key": tls[1], "tls_client_ca": tls[2]}
+        if native is not None:  # NativeExecutor: ordinary requests for its models never reach _on_request
+            kwargs["native"] = native
         self._front = pyext().HttpFront(host, int(port), int(reactors), self._on_request, None, **kwargs)
 
     def start(self):
