@@ -66,7 +66,7 @@ def test_grpc_wire_requests_run_natively_and_match(servers, batch):
         np.testing.assert_array_equal(answers[0][1], a - b)
 
 
-def test_int8_kernel_and_identity_fall_back_cleanly(servers):
+def test_int8_and_identity_kernels(servers):
     on, off = servers
     a = np.arange(-8, 8, dtype=np.int8).reshape(1, 16) * 15
     b = np.full((1, 16), 100, dtype=np.int8)
@@ -79,7 +79,10 @@ def test_int8_kernel_and_identity_fall_back_cleanly(servers):
             x = np.arange(32, dtype=np.int32).reshape(1, 32)
             inp = grpcclient.InferInput("INPUT0", [1, 32], "INT32").set_data_from_numpy(x)
             np.testing.assert_array_equal(c.infer("custom_identity_int32", [inp]).as_numpy("OUTPUT0"), x)
-    assert _handled(on) == before + 1  # the model without a kernel went to Python
+            # a request parameter (here: the delay knob) sends the same model through Python
+            slow = c.infer("custom_identity_int32", [inp], parameters={"execute_delay_ms": 1})
+            np.testing.assert_array_equal(slow.as_numpy("OUTPUT0"), x)
+    assert _handled(on) == before + 2  # both have kernels: add_sub on INT8, identity with a free dimension
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 

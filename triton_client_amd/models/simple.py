@@ -270,6 +270,7 @@ class CustomIdentityInt32(Model):
 
     name = "custom_identity_int32"
     max_batch_size = 1024
+    native_kernel = "identity"  # requests without parameters (no delay asked for) are answered in C++
     inputs = [TensorSpec("INPUT0", "INT32", [-1])]
     outputs = [TensorSpec("OUTPUT0", "INT32", [-1])]
 

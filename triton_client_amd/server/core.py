@@ -645,8 +645,8 @@ class InferenceCore:
             return
         model = lm.model
         kernel = getattr(model, "native_kernel", None)
-        eligible = present and kernel and getattr(model, "inline", False) and model.device == "cpu" \
-            and not model.parameters and not model.decoupled
+        eligible = present and kernel and model.device == "cpu" and not model.parameters and not model.decoupled \
+            and not getattr(model, "sequence", False)
         if not eligible:
             executor.remove_model(model.name)
             return
