@@ -415,6 +415,49 @@ def measure_image_client(args, url, device):
         pipe.close()
 
 
+def measure_secondary(args, device, dist):
+    """The other configurations of the benchmark set, each on this rank's own server and GPU:
+    `simple` over HTTP + system shared memory, `simple` over gRPC with tensors on the wire,
+    `simple_string` (BYTES) over gRPC + HIP shared memory, `repeat_int32` (decoupled, 16 responses
+    per request) over gRPC streams.  Closed loop at concurrency 16, two 1 s windows each; with
+    several ranks the throughputs are summed over the GPUs and the latencies are the worst rank's."""
+    import contextlib
+
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from secondary_bench import run_configs
+
+    names = ["simple_http_sysshm", "simple_grpc_wire", "string_grpc_hipshm", "decoupled_stream"]
+    rates, lats, error = [0.0] * 4, [0.0] * 8, None
+    try:
+        with contextlib.redirect_stdout(sys.stderr):  # the analyzer reports on stdout; ours carries one JSON line
+            lines = {line["config"]: line for line in run_configs(gpu=device, window_ms=1000)}
+        for i, name in enumerate(names):
+            line = lines[name]
+            rates[i] = float(line["responses_per_sec"] if name == "decoupled_stream" else line["infer_per_sec"])
+            lats[2 * i], lats[2 * i + 1] = float(line["p50_us"]), float(line["p99_us"])
+    except BaseException as e:  # noqa: BLE001 - reported, and the collectives below still run on every rank
+        error = f"{type(e).__name__}: {e}"[:500]
+    ok = 0.0 if error else 1.0
+    if dist is not None:
+        t = torch.tensor(rates, device=args.reduce_device, dtype=torch.float64)
+        dist.all_reduce(t)
+        rates = [float(v) for v in t.tolist()]
+        t = torch.tensor(lats + [-ok], device=args.reduce_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lats, ok = [float(v) for v in t[:8].tolist()], -float(t[8].item())
+    if ok < 1.0:
+        return {"error": error or "a configuration failed on another rank"}
+    out = {}
+    for i, name in enumerate(names):
+        key = "responses_per_sec" if name == "decoupled_stream" else "infer_per_sec"
+        out[name] = {key: round(rates[i], 1), "p50_latency_us": round(lats[2 * i], 1),
+                     "p99_latency_us": round(lats[2 * i + 1], 1), "concurrency_per_gpu": 16}
+    out["decoupled_stream"]["responses_per_request"] = 16
+    return out
+
+
 def measure_fanout(args, world):
     """``resnet50_sharded`` on GPU 0 with one replica process per further GPU: requests of
     ``32 x replicas`` images in HIP shared memory, split over the replicas and gathered into
@@ -550,6 +593,8 @@ def main():
         server.stop()
     if dist is not None:
         dist.barrier()
+    if not args.no_extras and args.client == "native" and args.mode == "serve":
+        extras["secondary"] = measure_secondary(args, device, dist)  # every rank takes part (collectives inside)
     if not args.no_extras and args.client == "native" and (args.mode == "fanout" or world > 1):
         # every rank's server is down; rank 0 serves resnet50_sharded with one replica per GPU
         # the other ranks wait on the host (a collective barrier would spin on their GPUs,

@@ -38,6 +38,12 @@ def _check(line, gpus, steps, warmup):
     for key in ("wire", "system_shm"):
         assert line["extra"][key]["infer_per_sec"] > 0
         assert line["extra"][key]["requests"] == 128 * gpus
+    # ... and so are the other configurations of the benchmark set, summed over the ranks
+    secondary = line["extra"]["secondary"]
+    assert "error" not in secondary, secondary
+    for key in ("simple_http_sysshm", "simple_grpc_wire", "string_grpc_hipshm"):
+        assert secondary[key]["infer_per_sec"] > 0 and secondary[key]["p50_latency_us"] <= secondary[key]["p99_latency_us"]
+    assert secondary["decoupled_stream"]["responses_per_sec"] > 0
 
 
 def test_single_rank_line():
