@@ -71,6 +71,9 @@ def parse_args():
                          "'0,0' rehearses three replicas on one GPU)")
     ap.add_argument("--fanout-modes", default="direct,rccl")
     ap.add_argument("--fanout-requests", type=int, default=384)
+    ap.add_argument("--fanout-timeout", type=float, default=420.0,
+                    help="seconds the whole fan-out measurement may take before it is abandoned")
+    ap.add_argument("--fanout-child", type=int, default=0, help=argparse.SUPPRESS)  # internal: world size
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=os.environ.get("TCA_BENCH_DIST_BACKEND", "nccl"),
                     help="nccl (= RCCL) for one rank per GPU; gloo only to rehearse several ranks on ONE GPU, "
                          "which RCCL refuses")
@@ -483,7 +486,7 @@ def measure_fanout(args, world):
         server = None
         try:
             t0 = time.perf_counter()
-            server = spawn_server(models=["resnet50_sharded"], gpu=0, startup_timeout=900,
+            server = spawn_server(models=["resnet50_sharded"], gpu=0, startup_timeout=200,
                                   env={"TCA_SHARD_DEVICES": ",".join(str(d) for d in devices), "TCA_SHARD_MODE": mode},
                                   extra_args=["--grpc-workers", "32"])
             start_s = time.perf_counter() - t0
@@ -502,6 +505,37 @@ def measure_fanout(args, world):
                 server.stop(timeout=40)
             torch.cuda.synchronize()
     return out
+
+
+def fanout_in_child(args, world):
+    """Runs :func:`measure_fanout` in a process of its own with a hard time limit: the replicas, their
+    IPC mappings and the RCCL group are set up across GPUs this process has never used, and nothing that
+    goes wrong there - a hang included - may take the benchmark's main result with it."""
+    import signal
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--fanout-child", str(world), "--protocol", args.protocol,
+           "--connections", str(args.connections), "--fanout-modes", args.fanout_modes, "--fanout-requests",
+           str(args.fanout_requests), "--batch", str(args.batch)]
+    if args.fanout_devices is not None:
+        cmd += ["--fanout-devices", args.fanout_devices]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
+                                                            "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
+                                                            "TORCHELASTIC_RUN_ID")}
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=args.fanout_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)  # the child, its server and the replica processes
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        return {"error": f"abandoned after {args.fanout_timeout:.0f} s"}
+    for line in reversed(out.splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": f"fan-out process ended with code {proc.returncode} and no result"}
 
 
 def launch_ranks(args):
@@ -533,6 +567,10 @@ def launch_ranks(args):
 
 def main():
     args = parse_args()
+    if args.fanout_child:
+        args.control_url = None
+        print(json.dumps(measure_fanout(args, args.fanout_child)), flush=True)
+        return None
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -606,7 +644,7 @@ def main():
             store = dist.distributed_c10d._get_default_store()
         if rank == 0:
             try:
-                extras["fanout"] = measure_fanout(args, world)
+                extras["fanout"] = fanout_in_child(args, world)
             finally:
                 if store is not None:
                     store.set("tca_fanout_done", "1")

@@ -38,8 +38,9 @@ def run_configs(gpu=None, window_ms=1000, emit=None):
         add("simple_grpc_wire", concurrency=16, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
             p99_us=rows[0]["p99_us"])
         shm = "hip" if gpu is not None else "system"
+        where = ["--devices", str(gpu)] if gpu is not None else []  # regions on the GPU the server runs on
         rows = perf(["-m", "simple_string", "-u", srv.grpc_url, "-i", "grpc", "--shared-memory", shm, "--native",
-                     "--concurrency-range", "16"] + common)
+                     "--concurrency-range", "16"] + where + common)
         add(f"string_grpc_{shm}shm", concurrency=16, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
             p99_us=rows[0]["p99_us"])
         rows = perf(["-m", "repeat_int32", "-u", srv.grpc_url, "-i", "grpc", "--native", "--streaming", "--shape", "IN:16",
