@@ -1,7 +1,7 @@
-"""Source-level checks of the non-Python, non-C++ clients.  There is no JDK / Go / Scala toolchain in
-the development image, so these cannot be compiled here: the JavaScript demo is syntax-checked and
-its pure helpers executed with node; Java sources get structural checks (package = directory,
-balanced delimiters, every imported in-tree class exists)."""
+"""The non-Python, non-C++ clients.  The JavaScript demo RUNS against the in-repo server (node is in
+the image; it falls back to node's own http2 module when @grpc/grpc-js is not installed).  There is no
+JDK / Go / Scala toolchain, so those cannot be compiled here: Java sources get structural checks
+(package = directory, balanced delimiters, every imported in-tree class exists)."""
 import os
 import re
 import shutil
@@ -24,6 +24,36 @@ def test_javascript_demo_syntax_and_helpers():
         "const b=Buffer.alloc(8);b.writeInt32LE(-5,0);b.writeInt32LE(7,4);"
         "const d=m.decodeInt32(b);if(d[0]!==-5||d[1]!==7)process.exit(2);" % js)
     subprocess.run(["node", "-e", script], check=True, timeout=60)
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+@pytest.mark.parametrize("grpc_impl", ["native", "grpcio"])
+def test_javascript_demo_runs_against_the_server(grpc_impl):
+    """Health, metadata, one inference with typed contents and a refused call, over gRPC from node."""
+    from triton_client_amd.server import Server
+
+    js = os.path.join(ROOT, "src", "grpc_generated", "javascript", "client.js")
+    with Server(models=["simple"], enable_http=False, grpc_impl=grpc_impl) as srv:
+        done = subprocess.run(["node", js, srv.grpc_url], capture_output=True, text=True, timeout=60)
+    assert done.returncode == 0, done.stdout[-1500:] + done.stderr[-1500:]
+    lines = done.stdout.strip().splitlines()
+    assert lines[0].startswith("model simple: inputs INPUT0, INPUT1") and lines[-1] == "PASS"
+    assert "3 + 1 = 4    3 - 1 = 2" in lines
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_javascript_wire_coding_matches_protobuf():
+    """The demo's hand-written request encoder against the real protobuf runtime."""
+    from triton_client_amd.grpc import service_pb2 as pb
+
+    js = os.path.join(ROOT, "src", "grpc_generated", "javascript", "client.js")
+    script = ("const m=require(%r);const r=m.buildRequest([1,-2,300000],[4,5,6]);r.id='abc';"
+              "process.stdout.write(m.encodeInferRequest(r).toString('hex'));" % js)
+    out = subprocess.run(["node", "-e", script], check=True, timeout=60, capture_output=True, text=True).stdout
+    msg = pb.ModelInferRequest.FromString(bytes.fromhex(out))
+    assert msg.model_name == "simple" and msg.id == "abc" and [o.name for o in msg.outputs] == ["OUTPUT0", "OUTPUT1"]
+    assert list(msg.inputs[0].contents.int_contents) == [1, -2, 300000] and list(msg.inputs[0].shape) == [1, 16]
+    assert msg.inputs[1].name == "INPUT1" and msg.inputs[1].datatype == "INT32"
 
 
 def _java_files():
