@@ -168,7 +168,7 @@ void CallPython(PyObject* fn, const char* fmt, ...) {
 template <typename Fn>
 void WithGil(PyGrpcFront* self, Fn&& fn) {
   if (self->funnel != nullptr) {
-    self->funnel->Push(std::forward<Fn>(fn));
+    self->funnel->Run(std::forward<Fn>(fn));
     return;
   }
   PyGILState_STATE gil = PyGILState_Ensure();

@@ -157,7 +157,7 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
     if (TryNative(self, call, req)) return;  // answered on this reactor thread, no interpreter
     if (self->funnel != nullptr) {
       auto shared = std::make_shared<tca::server::HttpServerFront::Request>(std::move(req));
-      self->funnel->Push([self, call, shared] { DeliverRequest(self, call, *shared); });
+      self->funnel->Run([self, call, shared] { DeliverRequest(self, call, *shared); });
       return;
     }
     PyGILState_STATE gil = PyGILState_Ensure();
@@ -167,7 +167,7 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   h.on_cancel = [self](uint64_t call) {
     if (self->on_cancel == nullptr || self->on_cancel == Py_None) return;
     if (self->funnel != nullptr) {
-      self->funnel->Push([self, call] { DeliverCancel(self, call); });
+      self->funnel->Run([self, call] { DeliverCancel(self, call); });
       return;
     }
     PyGILState_STATE gil = PyGILState_Ensure();
