@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import base64
 import json
+import math
 import threading
 import time
 from dataclasses import dataclass, field
@@ -460,7 +461,7 @@ def _shape_matches(dims, shape):
 
 def _decode_wire(datatype, shape, raw, name, model):
     """Wire bytes -> ndarray of ``shape``."""
-    count = int(np.prod(shape)) if len(shape) else 1
+    count = math.prod(shape) if len(shape) else 1
     if datatype == "BYTES":
         arr = deserialize_bytes_tensor(raw)
         if arr.size != count:
@@ -485,7 +486,7 @@ def _decode_wire(datatype, shape, raw, name, model):
 
 def _decode_json(datatype, shape, data, name):
     flat = np.array(data, dtype=object).reshape(-1).tolist() if isinstance(data, list) else [data]
-    count = int(np.prod(shape)) if len(shape) else 1
+    count = math.prod(shape) if len(shape) else 1
     if len(flat) != count:
         raise ServerError(f"unexpected number of elements {len(flat)} in 'data' for input '{name}', expecting {count}")
     if datatype == "BYTES":
@@ -586,6 +587,9 @@ class LoadedModel:
         self.request_counter = 0
         self.device_index = device_index
         self.batcher = None
+        # signature lookups of the request path (the model's tensor lists do not change after load)
+        self.in_specs = {t.name: t for t in model.inputs}
+        self.out_specs = {t.name: t for t in model.outputs}
 
 
 class InferenceCore:
@@ -826,7 +830,7 @@ class InferenceCore:
 
         Returns ``(inputs: dict, batch: int, device_views: set)``."""
         model = lm.model
-        specs = {t.name: t for t in model.inputs}
+        specs = lm.in_specs
         seen = set()
         inputs = {}
         batch = 0
@@ -904,7 +908,7 @@ class InferenceCore:
             raise ServerError(f"Invalid offset + byte size for shared memory region: '{ref.region}'", 400)
         if gpu and t.datatype != "BYTES":
             itemsize = 2 if t.datatype == "BF16" else np.dtype(triton_to_np_dtype(t.datatype)).itemsize
-            need = (int(np.prod(shape)) if len(shape) else 1) * itemsize
+            need = (math.prod(shape) if len(shape) else 1) * itemsize
             if need > ref.byte_size:
                 raise ServerError(
                     f"input '{t.name}' for model '{model.name}' needs {need} bytes, but the request gives it "
@@ -940,7 +944,7 @@ class InferenceCore:
         from ..utils import hip_shared_memory as hipshm
 
         shape = ([batch] if lm.model.max_batch_size > 0 else []) + list(spec.dims)
-        need = int(np.prod(shape)) * np.dtype(triton_to_np_dtype(spec.datatype)).itemsize
+        need = math.prod(shape) * np.dtype(triton_to_np_dtype(spec.datatype)).itemsize
         if need > ro.shm.byte_size or ro.shm.offset + need > entry[1]:
             raise ServerError(
                 f"shared memory size specified with the request for output '{ro.name}' ({ro.shm.byte_size} bytes) "
@@ -1070,7 +1074,7 @@ class InferenceCore:
             self._inject_faults(lm, req)
             t0 = time.perf_counter_ns()
             inputs, batch, stable = self._prepare_inputs(lm, req)
-            out_specs = {t.name: t for t in model.outputs}
+            out_specs = lm.out_specs
             requested = req.outputs
             if requested:
                 for ro in requested:

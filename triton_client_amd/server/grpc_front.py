@@ -40,23 +40,38 @@ def _param_value(p):
     return getattr(p, kind) if kind else None
 
 
+def _shm_ref(params):
+    """``ShmRef`` out of a tensor's parameter map, or None when it names no region."""
+    region = params.get("shared_memory_region")
+    if region is None:
+        return None
+    size = params.get("shared_memory_byte_size")
+    offset = params.get("shared_memory_offset")
+    return ShmRef(_param_value(region), int(_param_value(size) or 0) if size is not None else 0,
+                  int(_param_value(offset) or 0) if offset is not None else 0)
+
+
 def request_from_proto(msg, streaming=False, raw=None):
     """``ModelInferRequest`` -> :class:`InferRequest`.  ``raw`` replaces the
     message's ``raw_input_contents`` (buffers a transport kept out of the parsed
     message to avoid copying them)."""
+    top = msg.parameters
     req = InferRequest(model_name=msg.model_name, model_version=msg.model_version, id=msg.id, streaming=streaming,
-                       parameters={k: _param_value(v) for k, v in msg.parameters.items()})
+                       parameters={k: _param_value(v) for k, v in top.items()} if len(top) else {})
     raw_contents = msg.raw_input_contents if raw is None else raw
     raw_iter = iter(raw_contents)
     use_raw = len(raw_contents) > 0
+    inputs = req.inputs
     for t in msg.inputs:
         it = InputTensor(name=t.name, datatype=t.datatype, shape=list(t.shape))
-        params = {k: _param_value(v) for k, v in t.parameters.items()}
+        params = t.parameters
+        shm = _shm_ref(params) if len(params) else None
+        if shm is not None:
+            it.shm = shm
+            inputs.append(it)
+            continue
         has_contents = t.HasField("contents") and t.contents.ByteSize() > 0
-        if "shared_memory_region" in params:
-            it.shm = ShmRef(params["shared_memory_region"], int(params.get("shared_memory_byte_size", 0)),
-                            int(params.get("shared_memory_offset", 0)))
-        elif use_raw:
+        if use_raw:
             if has_contents:
                 raise ServerError(
                     f"contents field must not be specified when using raw_input_contents for '{t.name}' for model "
@@ -87,15 +102,17 @@ def request_from_proto(msg, streaming=False, raw=None):
                     f"unexpected number of elements {arr.size} in contents for input '{t.name}'") from None
         else:
             raise ServerError(f"input '{t.name}' for model '{msg.model_name}' has no data")
-        req.inputs.append(it)
+        inputs.append(it)
     if len(msg.outputs):
         req.outputs = []
         for o in msg.outputs:
-            params = {k: _param_value(v) for k, v in o.parameters.items()}
-            ro = RequestedOutput(name=o.name, class_count=int(params.get("classification", 0) or 0))
-            if "shared_memory_region" in params:
-                ro.shm = ShmRef(params["shared_memory_region"], int(params.get("shared_memory_byte_size", 0)),
-                                int(params.get("shared_memory_offset", 0)))
+            params = o.parameters
+            if len(params):
+                k = params.get("classification")
+                ro = RequestedOutput(name=o.name, class_count=int(_param_value(k) or 0) if k is not None else 0)
+                ro.shm = _shm_ref(params)
+            else:
+                ro = RequestedOutput(name=o.name)
             req.outputs.append(ro)
     return req
 
