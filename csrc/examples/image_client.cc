@@ -31,6 +31,7 @@
 #include "example_utils.h"
 #include "tca/codec.h"
 #include "tca/image_io.h"
+#include "tca/model_info.h"
 
 namespace {
 
@@ -139,36 +140,32 @@ tca::Error Preprocess(const Image& img, const ModelInfo& m, Scale scale, std::ve
 }
 
 tca::Error ParseModel(const std::string& metadata, const std::string& config, ModelInfo* m) {
-  tca::json::Value md, cfg_doc;
-  TCA_RETURN_IF_ERROR(tca::json::Parse(metadata, &md));
-  TCA_RETURN_IF_ERROR(tca::json::Parse(config, &cfg_doc));
-  // gRPC wraps the configuration in a response message: {"config": {...}}
-  tca::json::Value& cfg = cfg_doc.Find("config") != nullptr ? *cfg_doc.Find("config") : cfg_doc;
-  if (md["inputs"].Size() != 1) return tca::Error("expecting 1 input, got " + std::to_string(md["inputs"].Size()));
-  if (md["outputs"].Size() != 1) return tca::Error("expecting 1 output, got " + std::to_string(md["outputs"].Size()));
-  if (cfg["input"].Size() != 1) return tca::Error("expecting 1 input in the model configuration");
-  const auto& in = md["inputs"][0];
-  const auto& out = md["outputs"][0];
-  if (out.GetString("datatype") != "FP32") return tca::Error("expecting output datatype to be FP32, model output is " + out.GetString("datatype"));
-  m->max_batch_size = static_cast<int>(cfg.GetInt("max_batch_size"));
+  tca::ModelMetadataInfo md;
+  tca::ModelConfigInfo cfg;  // either protocol's document (tca/model_info.h)
+  TCA_RETURN_IF_ERROR(tca::ParseModelMetadata(metadata, &md));
+  TCA_RETURN_IF_ERROR(tca::ParseModelConfig(config, &cfg));
+  if (md.inputs.size() != 1) return tca::Error("expecting 1 input, got " + std::to_string(md.inputs.size()));
+  if (md.outputs.size() != 1) return tca::Error("expecting 1 output, got " + std::to_string(md.outputs.size()));
+  if (cfg.inputs.size() != 1) return tca::Error("expecting 1 input in the model configuration");
+  const tca::TensorInfo& in = md.inputs[0];
+  const tca::TensorInfo& out = md.outputs[0];
+  if (out.datatype != "FP32") return tca::Error("expecting output datatype to be FP32, model output is " + out.datatype);
+  m->max_batch_size = static_cast<int>(cfg.max_batch_size);
+  const size_t b = m->max_batch_size > 0 ? 1 : 0;
   // output must be a vector (all other dims 1)
   size_t non_one = 0;
-  const auto& oshape = out.Find("shape")->Items();
-  for (size_t i = m->max_batch_size > 0 ? 1 : 0; i < oshape.size(); ++i) non_one += oshape[i].AsInt() > 1;
+  for (size_t i = b; i < out.shape.size(); ++i) non_one += out.shape[i] > 1;
   if (non_one > 1) return tca::Error("expecting model output to be a vector");
-  const auto& ishape = in.Find("shape")->Items();
-  const size_t expected_dims = 3 + (m->max_batch_size > 0 ? 1 : 0);
-  if (ishape.size() != expected_dims) return tca::Error("expecting input to have " + std::to_string(expected_dims) + " dimensions");
-  const std::string format = cfg["input"][0].GetString("format", "FORMAT_NONE");
+  if (in.shape.size() != 3 + b) return tca::Error("expecting input to have " + std::to_string(3 + b) + " dimensions");
+  const std::string& format = cfg.inputs[0].format;
   if (format != "FORMAT_NCHW" && format != "FORMAT_NHWC") return tca::Error("unexpected input format " + format + ", expecting FORMAT_NCHW or FORMAT_NHWC");
   m->nhwc = format == "FORMAT_NHWC";
-  const size_t b = m->max_batch_size > 0 ? 1 : 0;
-  if (m->nhwc) { m->h = ishape[b].AsInt(); m->w = ishape[b + 1].AsInt(); m->c = ishape[b + 2].AsInt(); }
-  else { m->c = ishape[b].AsInt(); m->h = ishape[b + 1].AsInt(); m->w = ishape[b + 2].AsInt(); }
+  if (m->nhwc) { m->h = static_cast<int>(in.shape[b]); m->w = static_cast<int>(in.shape[b + 1]); m->c = static_cast<int>(in.shape[b + 2]); }
+  else { m->c = static_cast<int>(in.shape[b]); m->h = static_cast<int>(in.shape[b + 1]); m->w = static_cast<int>(in.shape[b + 2]); }
   if (m->c != 1 && m->c != 3) return tca::Error("expecting 1 or 3 channels, got " + std::to_string(m->c));
-  m->input_name = in.GetString("name");
-  m->output_name = out.GetString("name");
-  m->input_datatype = in.GetString("datatype");
+  m->input_name = in.name;
+  m->output_name = out.name;
+  m->input_datatype = in.datatype;
   return tca::Error::Success();
 }
 

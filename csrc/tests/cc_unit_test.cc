@@ -12,6 +12,7 @@
 #include "tca/codec.h"
 #include "tca/http_client.h"
 #include "tca/json.h"
+#include "tca/model_info.h"
 #include "tca/shm_utils.h"
 
 namespace tc = tca::client;
@@ -36,6 +37,47 @@ TEST(JsonRoundTrip) {
   EXPECT_TRUE(!tca::json::Parse("{\"a\":}", &bad).IsOk());
   EXPECT_TRUE(!tca::json::Parse("[1,2", &bad).IsOk());
   EXPECT_TRUE(!tca::json::Parse("{} x", &bad).IsOk());
+}
+
+TEST(TypedMetadataViews) {
+  // HTTP form of the documents
+  tca::ModelMetadataInfo md;
+  ASSERT_OK(tca::ParseModelMetadata(
+      R"({"name":"resnet50","versions":["1"],"platform":"pytorch_rocm","inputs":[{"name":"input","datatype":"FP16","shape":[-1,3,224,224]}],"outputs":[{"name":"output","datatype":"FP32","shape":[-1,1000]}]})",
+      &md));
+  EXPECT_EQ(md.name, std::string("resnet50"));
+  EXPECT_EQ(md.versions.size(), size_t(1));
+  EXPECT_EQ(md.inputs[0].shape.size(), size_t(4));
+  EXPECT_EQ(md.inputs[0].shape[0], int64_t(-1));
+  EXPECT_EQ(md.outputs[0].datatype, std::string("FP32"));
+  tca::ModelConfigInfo cfg;
+  ASSERT_OK(tca::ParseModelConfig(
+      R"({"name":"resnet50","platform":"pytorch_rocm","max_batch_size":128,"input":[{"name":"input","data_type":"TYPE_FP16","format":"FORMAT_NCHW","dims":[3,224,224]}],"output":[{"name":"output","data_type":"TYPE_FP32","dims":[1000]}],"dynamic_batching":{}})",
+      &cfg));
+  EXPECT_EQ(cfg.max_batch_size, int64_t(128));
+  EXPECT_EQ(cfg.inputs[0].datatype, std::string("FP16"));
+  EXPECT_EQ(cfg.inputs[0].format, std::string("FORMAT_NCHW"));
+  EXPECT_TRUE(cfg.dynamic_batching && !cfg.decoupled && !cfg.sequence_batching);
+  // gRPC form: wrapped configuration, 64-bit integers as strings, STRING for BYTES
+  ASSERT_OK(tca::ParseModelConfig(
+      R"({"config":{"name":"repeat","max_batch_size":"0","input":[{"name":"IN","data_type":"TYPE_STRING","dims":["-1"]}],"model_transaction_policy":{"decoupled":true}}})",
+      &cfg));
+  EXPECT_EQ(cfg.name, std::string("repeat"));
+  EXPECT_EQ(cfg.max_batch_size, int64_t(0));
+  EXPECT_EQ(cfg.inputs[0].datatype, std::string("BYTES"));
+  EXPECT_EQ(cfg.inputs[0].shape[0], int64_t(-1));
+  EXPECT_TRUE(cfg.decoupled);
+  std::vector<tca::RepositoryEntry> index;
+  ASSERT_OK(tca::ParseRepositoryIndex(R"([{"name":"a","version":"1","state":"READY"},{"name":"b"}])", &index));
+  EXPECT_EQ(index.size(), size_t(2));
+  EXPECT_EQ(index[0].state, std::string("READY"));
+  ASSERT_OK(tca::ParseRepositoryIndex(R"({"models":[{"name":"c","state":"UNAVAILABLE","reason":"x"}]})", &index));
+  EXPECT_EQ(index[0].reason, std::string("x"));
+  tca::ServerInfo server;
+  ASSERT_OK(tca::ParseServerMetadata(R"({"name":"triton","version":"2.0","extensions":["classification","binary_tensor_data"]})", &server));
+  EXPECT_EQ(server.extensions.size(), size_t(2));
+  EXPECT_TRUE(!tca::ParseModelMetadata("[1,2]", &md).IsOk());
+  EXPECT_TRUE(!tca::ParseModelConfig("{\"config\":{}}", &cfg).IsOk());
 }
 
 TEST(Base64) {
