@@ -74,7 +74,8 @@ def parse_args():
     ap.add_argument("--fanout-timeout", type=float, default=420.0,
                     help="seconds the whole fan-out measurement may take before it is abandoned")
     ap.add_argument("--fanout-child", type=int, default=0, help=argparse.SUPPRESS)  # internal: world size
-    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=os.environ.get("TCA_BENCH_DIST_BACKEND", "nccl"),
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=os.environ.get("TCA_BENCH_DIST_BACKEND",
+                                                                                       "nccl"),
                     help="nccl (= RCCL) for one rank per GPU; gloo only to rehearse several ranks on ONE GPU, "
                          "which RCCL refuses")
     return ap.parse_args()

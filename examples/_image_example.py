@@ -56,14 +56,16 @@ def parse_model(metadata, config):
     name = _field(metadata, "name")
     if _field(out, "datatype") != "FP32":
         fail(f"expecting output datatype to be FP32, model '{name}' output type is {_field(out, 'datatype')}")
-    max_batch = int(_field(config, "max_batch_size") if not isinstance(config, dict) else config.get("max_batch_size", 0))
+    max_batch = int(_field(config, "max_batch_size") if not isinstance(config,
+                                                                       dict) else config.get("max_batch_size", 0))
     batched = max_batch > 0
     out_shape = [int(d) for d in _field(out, "shape")]
     if sum(1 for d in out_shape[(1 if batched else 0):] if d > 1) > 1:
         fail("expecting model output to be a vector")
     in_shape = [int(d) for d in _field(inp, "shape")]
     if len(in_shape) != 3 + (1 if batched else 0):
-        fail(f"expecting input to have {3 + (1 if batched else 0)} dimensions, model '{name}' input has {len(in_shape)}")
+        fail(f"expecting input to have {3 + (1 if batched else 0)} dimensions, model '{name}' input has "
+             f"{len(in_shape)}")
     fmt = _field(cfg_in, "format")
     if not isinstance(fmt, str):  # protobuf enum value: 1 = NHWC, 2 = NCHW
         fmt = {1: "FORMAT_NHWC", 2: "FORMAT_NCHW"}.get(int(fmt), "FORMAT_NONE")

@@ -27,7 +27,8 @@ if __name__ == "__main__":
         fail("an image file or folder is required")
     stub = service_pb2_grpc.GRPCInferenceServiceStub(grpc.insecure_channel(flags.url))
     try:
-        metadata = stub.ModelMetadata(service_pb2.ModelMetadataRequest(name=flags.model_name, version=flags.model_version))
+        metadata = stub.ModelMetadata(service_pb2.ModelMetadataRequest(name=flags.model_name,
+                                                                       version=flags.model_version))
         config = stub.ModelConfig(service_pb2.ModelConfigRequest(name=flags.model_name, version=flags.model_version))
     except grpc.RpcError as e:
         fail("failed to query the model: " + str(e))

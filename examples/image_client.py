@@ -5,7 +5,6 @@ shared memory), sends batches synchronously / asynchronously / over a gRPC
 stream and prints the top-K classes.  (Reference:
 ``src/python/examples/image_client.py``.)"""
 import queue
-import sys
 from functools import partial
 
 from _common import fail, parser
@@ -34,7 +33,8 @@ if __name__ == "__main__":
                     help="host: numpy/Pillow on the CPU; hip: fused kernel into device shared memory")
     ap.add_argument("-g", "--device", type=int, default=0, help="GPU ordinal for --preprocess hip")
     ap.add_argument("--ring-depth", type=int, default=4,
-                    help="--preprocess hip: batch slots in the input region (requests in flight while the next is filled)")
+                    help="--preprocess hip: batch slots in the input region (requests in flight while the next is "
+                         "filled)")
     ap.add_argument("image_filename", nargs="?", default=None, help="Input image / input folder")
     flags = ap.parse_args()
     grpc_mode = flags.protocol.lower() == "grpc"

@@ -55,7 +55,8 @@ setup(
     packages=find_packages(include=["triton_client_amd*", "tritonclient*", "tritonhttpclient*", "tritongrpcclient*",
                                     "tritonclientutils*", "tritonshmutils*"]),
     package_data={
-        "triton_client_amd": ["_lib/*.so", "_lib/tca_loadgen", "grpc/protos/*.proto", "models/miopen_db/*.txt", "ops/*.json"],
+        "triton_client_amd": ["_lib/*.so", "_lib/tca_loadgen", "grpc/protos/*.proto", "models/miopen_db/*.txt",
+                              "ops/*.json"],
     },
     install_requires=_req("requirements.txt"),
     extras_require=extras,

@@ -62,7 +62,8 @@ def test_cc_timeout_and_leak_tools_grpc(built, server):
     out = _run([tool, "-i", "grpc", "-u", server.grpc_url, "-p", "-t", "1"])
     assert "20 control calls" in out and "0 unexpected outcomes" in out and "PASS" in out
     assert "PASS" in _run([os.path.join(built, "memory_leak_test"), "-i", "grpc", "-u", server.grpc_url, "-r", "200"])
-    assert "PASS" in _run([os.path.join(built, "memory_leak_test"), "-i", "grpc", "-u", server.grpc_url, "-r", "200", "-R"])
+    assert "PASS" in _run([os.path.join(built, "memory_leak_test"), "-i", "grpc", "-u", server.grpc_url, "-r", "200",
+                           "-R"])
 
 
 def test_native_loadgen(built, server):
@@ -147,7 +148,8 @@ def _write_adam7_png(path, pixels):
 
     h, w, _ = pixels.shape
     raw = b""
-    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2),
+                           (0, 1, 1, 2)):
         sub = pixels[y0::dy, x0::dx]
         if sub.size == 0:
             continue
@@ -232,10 +234,12 @@ def test_cpp_image_client_png_files(built, server, tmp_path, protocol, mode):
         Image.fromarray(rng.integers(0, 256, size=(60 + 8 * i, 80, 3), dtype=np.uint8)).save(path)
         files.append(path)
     url = server.http_url if protocol == "http" else server.grpc_url
-    out = _run([os.path.join(built, "image_client"), "-u", url, "-i", protocol, "-m", "tiny_classifier", "-b", "2", "-c", "2",
+    out = _run([os.path.join(built, "image_client"), "-u", url, "-i", protocol, "-m", "tiny_classifier", "-b", "2",
+                "-c", "2",
                 "-s", "INCEPTION", *mode, *files])
     assert "PASS" in out and out.count("Image '") == 4
-    ref = _run([os.path.join(built, "image_client"), "-u", server.http_url, "-m", "tiny_classifier", "-b", "2", "-c", "2",
+    ref = _run([os.path.join(built, "image_client"), "-u", server.http_url, "-m", "tiny_classifier", "-b", "2", "-c",
+                "2",
                 "-s", "INCEPTION", *files])
     pick = lambda text: [line for line in text.splitlines() if line.startswith("    ")]  # noqa: E731
     assert pick(out) == pick(ref)

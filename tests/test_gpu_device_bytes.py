@@ -60,7 +60,8 @@ def test_string_add_sub_golden_bytes(served, batch):
     b = rng.integers(-10 ** 6, 10 ** 6, size=(batch, 16))
     a[0, 0], b[0, 0] = 0, 0
     sa = np.array([str(v).encode() for v in a.reshape(-1)], dtype=object).reshape(batch, 16)
-    sb = np.array([(" +%d " % v if v >= 0 else str(v)).encode() for v in b.reshape(-1)], dtype=object).reshape(batch, 16)
+    sb = np.array([(" +%d " % v if v >= 0 else str(v)).encode() for v in b.reshape(-1)],
+                  dtype=object).reshape(batch, 16)
     blob_a, blob_b = serialize_byte_tensor(sa).item(), serialize_byte_tensor(sb).item()
     cap = 4096
     with g.InferenceServerClient(served.grpc_url) as c:
@@ -73,7 +74,8 @@ def test_string_add_sub_golden_bytes(served, batch):
             res = c.infer("simple_string", ins, outputs=outs)
             assert res.get_output("OUTPUT0").shape == [batch, 16]
             for name, expect in (("out0", a + b), ("out1", a - b)):
-                want = serialize_byte_tensor(np.array([str(v).encode() for v in expect.reshape(-1)], dtype=object)).item()
+                want = serialize_byte_tensor(np.array([str(v).encode() for v in expect.reshape(-1)],
+                                                      dtype=object)).item()
                 raw = hipshm.get_contents_as_numpy(handles[f"{tag}_{name}"], np.uint8, [len(want)])
                 assert raw.tobytes() == want  # byte for byte the reference wire form
                 got = hipshm.get_contents_as_numpy(handles[f"{tag}_{name}"], np.object_, [batch, 16])

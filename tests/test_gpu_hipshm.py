@@ -221,7 +221,8 @@ def test_concurrent_clients_get_their_own_answers(hipshm, gpu_server):
     rng = np.random.default_rng(3)
     n_clients, rounds = 12, 6
     batches = [1, 2, 3, 4, 5, 8, 8, 8, 6, 7, 8, 1]
-    inputs = [(rng.standard_normal((b, 3, 224, 224)) * (0.5 + 0.1 * i)).astype(np.float16) for i, b in enumerate(batches)]
+    inputs = [(rng.standard_normal((b, 3, 224, 224)) * (0.5 + 0.1 * i)).astype(np.float16) for i,
+              b in enumerate(batches)]
     expected = []
     with mod.InferenceServerClient(gpu_server.grpc_url) as c:
         for x in inputs:  # one at a time: no merging
@@ -254,7 +255,8 @@ def test_concurrent_clients_get_their_own_answers(hipshm, gpu_server):
                 start.wait(timeout=60)
                 for _ in range(rounds):
                     r = c.infer("resnet50", [t], outputs=[o])
-                    got = hipshm.get_contents_as_numpy(regions[1], np.float32, [b, 1000]) if regions else r.as_numpy("output")
+                    got = hipshm.get_contents_as_numpy(regions[1], np.float32,
+                                                       [b, 1000]) if regions else r.as_numpy("output")
                     if not np.allclose(got, want, rtol=2e-2, atol=2e-2):
                         errors.append((i, float(np.abs(got - want).max())))
                         return

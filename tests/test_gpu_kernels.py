@@ -38,7 +38,8 @@ def test_preprocess_matches_pillow_bit_exact(torch, src_hw, channels, layout):
 @pytest.mark.parametrize("dtype,np_dtype,scaling", [("FP16", np.float16, "INCEPTION"), ("FP32", np.float32, "VGG"),
                                                     ("INT8", np.int8, "VGG"), ("UINT8", np.uint8, "NONE"),
                                                     ("BF16", None, "INCEPTION"),
-                                                    ("FP32", np.float32, ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)))])
+                                                    ("FP32", np.float32, ((0.485, 0.456, 0.406),
+                                                                          (0.229, 0.224, 0.225)))])
 def test_preprocess_scaling_and_cast(torch, dtype, np_dtype, scaling):
     from triton_client_amd.ops.preprocess import Preprocessor, reference_preprocess
 
@@ -272,7 +273,8 @@ def _nhwc(t):
     return t.contiguous(memory_format=_torch.channels_last)
 
 
-@pytest.mark.parametrize("variant", ["auto", "128x128", "128x64", "64x64", "128x128w8", "256x128w8", "128x64w8", "64x64w8", "128x256w8"])
+@pytest.mark.parametrize("variant", ["auto", "128x128", "128x64", "64x64", "128x128w8", "256x128w8", "128x64w8",
+                                     "64x64w8", "128x256w8"])
 @pytest.mark.parametrize("shape", [
     # batch, H, W, Cin, Cout, stride, residual, relu
     (2, 56, 56, 64, 256, 1, True, True),
@@ -476,7 +478,8 @@ def test_conv3x3_pointwise_next_conv_fused(torch, shape, mid, n3):
     res = _nhwc(torch.randn(b, cout, oh, ow, device="cuda", generator=gen).half())
     y_ref = conv.conv2d_pointwise(x, w1, b1, w2, b2, res, relu=True, stride=stride, padding=1)
     t_ref = torch.nn.functional.conv2d(y_ref.float(), w3.float().reshape(n3, cout, 1, 1), b3.float()).clamp_min(0)
-    y, t = conv.conv2d_pointwise(x, w1, b1, w2, b2, res, relu=True, stride=stride, padding=1, next_weight=w3, next_bias=b3)
+    y, t = conv.conv2d_pointwise(x, w1, b1, w2, b2, res, relu=True, stride=stride, padding=1, next_weight=w3,
+                                 next_bias=b3)
     assert torch.equal(y, y_ref)
     assert t.shape == t_ref.shape
     torch.testing.assert_close(t.float(), t_ref, rtol=4e-3, atol=4e-3)

@@ -119,7 +119,8 @@ def test_gpu_ensemble_matches_client_side_preprocessing():
             raw = np.array(blobs, dtype=np.object_).reshape(3, 1)
             inp = g.InferInput("INPUT", [3, 1], "BYTES").set_data_from_numpy(raw)
             got = c.infer("preprocess_resnet50_ensemble", [inp]).as_numpy("OUTPUT")
-            x = np.stack([reference_preprocess(p, 224, 224, 3, "NCHW", np.float16, "INCEPTION", "pil") for p in pictures])
+            x = np.stack([reference_preprocess(p, 224, 224, 3, "NCHW", np.float16, "INCEPTION",
+                                               "pil") for p in pictures])
             direct = g.InferInput("input", [3, 3, 224, 224], "FP16").set_data_from_numpy(x)
             ref = c.infer("resnet50", [direct]).as_numpy("output")
             assert got.shape == ref.shape == (3, 1000)
@@ -130,6 +131,7 @@ def test_gpu_ensemble_matches_client_side_preprocessing():
             top = c.infer("preprocess_resnet50_ensemble", [inp], outputs=[out]).as_numpy("OUTPUT")
             assert top.shape == (3, 2) and top[0, 0].decode().split(":")[1] == str(int(ref[0].argmax()))
             # a broken file is a clean request error
-            bad = g.InferInput("INPUT", [1, 1], "BYTES").set_data_from_numpy(np.array([[b"not an image"]], dtype=np.object_))
+            bad = g.InferInput("INPUT", [1, 1], "BYTES").set_data_from_numpy(np.array([[b"not an image"]],
+                                                                                      dtype=np.object_))
             with pytest.raises(Exception, match="unable to decode image"):
                 c.infer("preprocess_resnet50_ensemble", [bad])

@@ -47,7 +47,8 @@ def _check(line, gpus, steps, warmup):
 
 
 def test_single_rank_line():
-    cmd = [sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--requests-per-step", "64", "--concurrency", "16",
+    cmd = [sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--requests-per-step", "64", "--concurrency",
+           "16",
            "--extra-requests", "128"]
     done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert done.returncode == 0, done.stderr[-2000:]

@@ -175,7 +175,8 @@ def test_errors_and_special_requests_take_the_general_path(servers):
             # request parameters, classification and a compressed request: answered, by Python
             r = c.infer("simple", _inputs(grpcclient, a, b), parameters={"note": "x"})
             np.testing.assert_array_equal(r.as_numpy("OUTPUT0"), a + b)
-            r = c.infer("simple", _inputs(grpcclient, a, b), outputs=[grpcclient.InferRequestedOutput("OUTPUT0", class_count=2)])
+            r = c.infer("simple", _inputs(grpcclient, a, b),
+                        outputs=[grpcclient.InferRequestedOutput("OUTPUT0", class_count=2)])
             assert r.as_numpy("OUTPUT0").shape == (1, 2)
             r = c.infer("simple", _inputs(grpcclient, a, b), model_version="1")  # the current version: native again
             np.testing.assert_array_equal(r.as_numpy("OUTPUT1"), a - b)

@@ -55,7 +55,8 @@ def test_cmake_build_install_and_find_package(tmp_path):
 
     run("cmake", "-S", os.path.join(root, "csrc"), "-B", build, "-DCMAKE_BUILD_TYPE=Release",
         "-DTCA_ENABLE_EXAMPLES=OFF", f"-DCMAKE_INSTALL_PREFIX={prefix}")
-    run("cmake", "--build", build, "-j", "8", "--target", "tcaclient", "tcaclient_static", "cc_unit_test", "tca_loadgen")
+    run("cmake", "--build", build, "-j", "8", "--target", "tcaclient", "tcaclient_static", "cc_unit_test",
+        "tca_loadgen")
     out = run("ctest", "-R", "cc_unit_test", "--output-on-failure", cwd=build)
     assert "100% tests passed" in out
     run("cmake", "--build", build, "-j", "8")

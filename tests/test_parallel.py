@@ -50,7 +50,8 @@ def _worker(rank, world, port, mode, batch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,batch", [(2, "scatter", 8), (2, "broadcast", 8), (3, "scatter", 8), (2, "scatter", 5)])
+@pytest.mark.parametrize("world,mode,batch", [(2, "scatter", 8), (2, "broadcast", 8), (3, "scatter", 8),
+                                              (2, "scatter", 5)])
 def test_fanout_gather_gloo(world, mode, batch):
     import torch.multiprocessing as mp
 
@@ -137,7 +138,8 @@ def test_sharded_client_sequences_and_streams():
                 assert error is None, error
                 rid = result.get_response().id
                 finals[rid] = int(result.as_numpy("OUTPUT")[0, 0])
-            assert all(finals[f"{sid}_0"] == 6 and finals[f"{sid}_2"] == 7 for sid in ("alpha", "beta", "gamma")), finals
+            assert all(finals[f"{sid}_0"] == 6 and finals[f"{sid}_2"] == 7 for sid in ("alpha", "beta",
+                                                                                       "gamma")), finals
 
             n = 6
             rep = [g.InferInput("IN", [n], "INT32").set_data_from_numpy(np.arange(n, dtype=np.int32)),

@@ -112,15 +112,18 @@ def test_native_streaming_drives_a_decoupled_model(two_servers):
 
     _build.build_cpp()
     a, _ = two_servers
-    base = ["-u", a.grpc_url, "-i", "grpc", "--native", "--concurrency-range", "4", "-p", "200", "--stability-windows", "2",
+    base = ["-u", a.grpc_url, "-i", "grpc", "--native", "--concurrency-range", "4", "-p", "200",
+            "--stability-windows", "2",
             "--warmup-ms", "100"]
-    rows = _run(["-m", "repeat_int32", "--streaming", "--shape", "IN:5", "--shape", "DELAY:5", "--shape", "WAIT:1"] + base)
+    rows = _run(["-m", "repeat_int32", "--streaming", "--shape", "IN:5", "--shape", "DELAY:5", "--shape",
+                 "WAIT:1"] + base)
     r = rows[0]
     assert r["errors"] == 0 and r["requests"] > 10
     assert r["responses_per_sec"] == pytest.approx(5 * r["requests_per_sec"], rel=0.1)
     # request/response models work over the stream too: one response per request
     rows = _run(["-m", "simple", "--streaming"] + base)
-    assert rows[0]["errors"] == 0 and rows[0]["responses_per_sec"] == pytest.approx(rows[0]["requests_per_sec"], rel=0.05)
+    assert rows[0]["errors"] == 0 and rows[0]["responses_per_sec"] == pytest.approx(rows[0]["requests_per_sec"],
+                                                                                    rel=0.05)
     with pytest.raises(SystemExit):  # without the stream a decoupled model cannot be measured
         _run(["-m", "repeat_int32", "--shape", "IN:5", "--shape", "DELAY:5", "--shape", "WAIT:1"] + base)
 

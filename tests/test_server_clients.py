@@ -703,10 +703,12 @@ def test_http_front_protocol_edges(impl):
         assert b"200 OK" in s.recv(65536)
         s.close()
         # Connection: close is honoured
-        out = _raw_http(port, b"GET /v2/health/ready HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n", expect_close=True)
+        out = _raw_http(port, b"GET /v2/health/ready HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n",
+                        expect_close=True)
         assert b"200 OK" in out and b"connection: close" in out.lower()
         # unknown endpoint and malformed JSON are 4xx with a JSON error, the connection survives
-        out = _raw_http(port, b"GET /v2/nothing HTTP/1.1\r\nHost: x\r\n\r\nGET /v2/health/live HTTP/1.1\r\nHost: x\r\n\r\n")
+        out = _raw_http(port,
+                        b"GET /v2/nothing HTTP/1.1\r\nHost: x\r\n\r\nGET /v2/health/live HTTP/1.1\r\nHost: x\r\n\r\n")
         assert b"404" in out.split(b"\r\n", 1)[0] and out.count(b"HTTP/1.1 200 OK") == 1
         bad = b"{not json"
         out = _raw_http(port, b"POST /v2/models/simple/infer HTTP/1.1\r\nHost: x\r\nContent-Length: %d\r\n\r\n" % len(bad) + bad)

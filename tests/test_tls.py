@@ -60,7 +60,8 @@ def cpp_bins():
 def _server(pki, grpc_impl, client_ca=None):
     from triton_client_amd.server import Server
 
-    return Server(models=["simple", "simple_sequence"], grpc_impl=grpc_impl, tls_cert=pki["server.pem"], tls_key=pki["server.key"],
+    return Server(models=["simple", "simple_sequence"], grpc_impl=grpc_impl, tls_cert=pki["server.pem"],
+                  tls_key=pki["server.key"],
                   tls_client_ca=client_ca)
 
 
@@ -105,7 +106,8 @@ def test_mutual_tls(pki, cpp_bins, grpc_impl):
         http = f"https://localhost:{srv._http_port}"
         grpc_url = f"localhost:{srv._grpc_port}"
         with_cert = ["--cert-file", pki["client.pem"], "--key-file", pki["client.key"]]
-        r = _run([os.path.join(cpp_bins, "simple_http_infer_client"), "-u", http, "--ca-certs", pki["ca.pem"], *with_cert])
+        r = _run([os.path.join(cpp_bins, "simple_http_infer_client"), "-u", http, "--ca-certs", pki["ca.pem"],
+                  *with_cert])
         assert r.returncode == 0 and "PASS" in r.stdout, r.stderr
         r = _run([os.path.join(cpp_bins, "simple_http_infer_client"), "-u", http, "--ca-certs", pki["ca.pem"]])
         assert r.returncode != 0, "the server must refuse a client without a certificate"

@@ -34,7 +34,8 @@ def build(dest, linux, version, skip_hip):
         for name in ("triton_client_amd", "tritonclient", "tritonhttpclient", "tritongrpcclient", "tritonclientutils",
                      "tritonshmutils", "requirements", "csrc"):
             shutil.copytree(os.path.join(ROOT, name), os.path.join(stage, name),
-                            ignore=shutil.ignore_patterns("__pycache__", "*.pyc", *(() if linux else ("*.so", "tca_loadgen"))))
+                            ignore=shutil.ignore_patterns("__pycache__", "*.pyc",
+                                                          *(() if linux else ("*.so", "tca_loadgen"))))
         for name in ("setup.py", "README.md"):
             shutil.copy(os.path.join(ROOT, name), stage)
         cmd = [sys.executable, "setup.py", "-q", "bdist_wheel", "-d", os.path.abspath(dest)]

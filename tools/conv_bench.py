@@ -133,7 +133,8 @@ def main():
                                                   ("eager", "lib+ep") + MFMA_VARIANTS) + f"  {best}",
                   flush=True)
     for b, t in totals.items():
-        print(f"batch {b}: sum over distinct layers (us): " + ", ".join(f"{k}={v:.1f}" for k, v in t.items()), flush=True)
+        print(f"batch {b}: sum over distinct layers (us): " + ", ".join(f"{k}={v:.1f}" for k, v in t.items()),
+              flush=True)
 
 
 if __name__ == "__main__":

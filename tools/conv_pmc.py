@@ -43,7 +43,8 @@ def main():
         wn = (torch.randn(args.next, args.expand, device=dev) / args.expand ** 0.5).half() if args.next else None
         bn = torch.randn(args.next, device=dev).half() if args.next else None
         for _ in range(args.iters):
-            conv.conv2d_pointwise(x, w4, bias, we, be, res, relu=True, stride=1, padding=k // 2, next_weight=wn, next_bias=bn)
+            conv.conv2d_pointwise(x, w4, bias, we, be, res, relu=True, stride=1, padding=k // 2, next_weight=wn,
+                                  next_bias=bn)
         torch.cuda.synchronize()
         flops = 2.0 * args.batch * args.hw * args.hw * args.cout * (args.cin * k * k + args.expand) + \
             2.0 * args.batch * args.hw * args.hw * args.expand * args.next

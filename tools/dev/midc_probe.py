@@ -11,7 +11,8 @@ for reactors, conns, inline in ((2, 4, 1), (2, 4, 0), (1, 4, 1), (2, 4, 1), (2, 
     os.environ["TCA_PERF_CONNECTIONS"] = str(conns)
     with spawn_server(models=["resnet50"], gpu=0, env={"TCA_GRPC_REACTORS": str(reactors),
                                                         "TCA_FUNNEL_INLINE": str(inline)}) as srv:
-        rows = perf(["-m", "resnet50", "-u", srv.grpc_url, "-i", "grpc", "-b", "8", "--native", "--shared-memory", "hip",
+        rows = perf(["-m", "resnet50", "-u", srv.grpc_url, "-i", "grpc", "-b", "8", "--native", "--shared-memory",
+                     "hip",
                      "--concurrency-range", "1:64:4", "--multiplicative-step", "-p", "1000", "--stability-windows", "2",
                      "--warmup-ms", "400"])
         print(f"RESULT reactors={reactors} connections={conns} inline={inline}: " +

@@ -11,8 +11,10 @@ from triton_client_amd.perf import main as perf
 from triton_client_amd.server import spawn_server
 
 with spawn_server(models=["resnet50"], gpu=0) as srv:
-    rows = perf(["-m", "resnet50", "-u", srv.grpc_url, "-i", "grpc", "-b", "8", "--native", "--shared-memory", os.environ.get("TCA_PROF_SHM", "none"),
-                 "--concurrency-range", os.environ.get("TCA_PROF_CONC", "64"), "-p", "2000", "--stability-windows", "2", "--warmup-ms", "400"])
+    rows = perf(["-m", "resnet50", "-u", srv.grpc_url, "-i", "grpc", "-b", "8", "--native", "--shared-memory",
+                 os.environ.get("TCA_PROF_SHM", "none"),
+                 "--concurrency-range", os.environ.get("TCA_PROF_CONC", "64"), "-p", "2000", "--stability-windows",
+                 "2", "--warmup-ms", "400"])
     print("RESULT", round(rows[0]["infer_per_sec"]), rows[0]["requests"])
 for name in sorted(os.listdir(out)):
     print("=====", name)

@@ -42,7 +42,8 @@ try:
         print("sharded repeat max diff", [float(np.abs(s[0] - v).max()) for v in s[1:]])
         ref = np.concatenate([a[0], b[0], plain(x[32:48])])
         for r in range(3):
-            print("rank", r, "rows vs plain: max diff", float(np.abs(s[0][16 * r:16 * r + 16] - ref[16 * r:16 * r + 16]).max()),
+            print("rank", r, "rows vs plain: max diff",
+                  float(np.abs(s[0][16 * r:16 * r + 16] - ref[16 * r:16 * r + 16]).max()),
                   "later run", float(np.abs(s[3][16 * r:16 * r + 16] - ref[16 * r:16 * r + 16]).max()))
         # the same 16 rows through a registered region with the plain model (graph on the region)
         inp16 = g.InferInput("input", [16, 3, 224, 224], "FP16")

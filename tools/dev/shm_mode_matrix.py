@@ -6,7 +6,8 @@ GPU = None if os.environ.get("TCA_HIPSHM_FAKE") == "1" else 0
 from triton_client_amd.perf import main as perf
 from triton_client_amd.server import spawn_server
 with spawn_server(models=["simple", "simple_string"], gpu=GPU) as srv:
-    common = ["-u", srv.grpc_url, "-i", "grpc", "--native", "--concurrency-range", "16", "-p", "800", "--stability-windows", "2", "--warmup-ms", "300"]
+    common = ["-u", srv.grpc_url, "-i", "grpc", "--native", "--concurrency-range", "16", "-p", "800",
+              "--stability-windows", "2", "--warmup-ms", "300"]
     for model in ("simple", "simple_string"):
         for shm in ("none", "system", "hip"):
             rows = perf(["-m", model, "--shared-memory", shm] + common)

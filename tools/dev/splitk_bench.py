@@ -45,7 +45,8 @@ def main():
         return start.elapsed_time(end) * 1e3 / (5 * args.reps)
 
     cols = [("auto", 1), ("auto", 0), ("64x64w8", 2), ("64x64w8", 4), ("64x64w8", 8), ("64x64", 4), ("128x64w8", 4)]
-    print(f"{'batch':>5} {'layer':>26} {'lib+ep':>8} " + " ".join(f"{v + '/' + str(k):>11}" for v, k in cols), flush=True)
+    print(f"{'batch':>5} {'layer':>26} {'lib+ep':>8} " + " ".join(f"{v + '/' + str(k):>11}" for v, k in cols),
+          flush=True)
     sums = {}
     for b in [int(v) for v in args.batches.split(",")]:
         layers = [(h, w, cin, cout, 1, s, r, relu) for (h, w, cin, cout, s, r, relu) in LAYERS] + \

@@ -6,7 +6,8 @@ import numpy as np
 import torch
 
 n = 16
-srcs = [np.random.default_rng(i).integers(0, 255, size=(8, 3, 224, 224), dtype=np.uint16).view(np.float16) for i in range(n)]
+srcs = [np.random.default_rng(i).integers(0, 255, size=(8, 3, 224, 224),
+                                          dtype=np.uint16).view(np.float16) for i in range(n)]
 pinned = [torch.empty(srcs[0].nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(4)]
 dev = torch.empty((128, 3, 224, 224), dtype=torch.float16, device="cuda")
 stream = torch.cuda.Stream()
@@ -36,7 +37,8 @@ def np_memcpy_only():
 def h2d_only():
     with torch.cuda.stream(stream):
         for i in range(n):
-            dev[(i % 16) * 8:(i % 16) * 8 + 8].copy_(pinned[i % 4].view(torch.float16).view(8, 3, 224, 224), non_blocking=True)
+            dev[(i % 16) * 8:(i % 16) * 8 + 8].copy_(pinned[i % 4].view(torch.float16).view(8, 3, 224, 224),
+                                                     non_blocking=True)
 
 
 def both():

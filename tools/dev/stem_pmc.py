@@ -20,7 +20,8 @@ def main():
     x = torch.randn(args.batch, 3, 224, 224, device="cuda", dtype=torch.float16)
     w = conv.pack_stem_weight(torch.randn(64, 3, 7, 7, device="cuda", dtype=torch.float16) * 0.05)
     b = torch.randn(64, device="cuda", dtype=torch.float16)
-    out = torch.empty(args.batch, 64, 56, 56, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    out = torch.empty(args.batch, 64, 56, 56, device="cuda",
+                      dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     for _ in range(args.iters):
         conv.stem_conv_pool(x, w, b, out=out)
     torch.cuda.synchronize()

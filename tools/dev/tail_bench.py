@@ -40,5 +40,7 @@ for batch in (8, 32, 128):
     from triton_client_amd.ops._device import lib as L
     s = lambda: torch.cuda.current_stream().cuda_stream
     pool = graph_time(lambda: L().tca_avgpool_launch(y.data_ptr(), feats.data_ptr(), batch, 49, 2048, s()))
-    lin = graph_time(lambda: L().tca_linear_launch(feats.data_ptr(), fc.weight.data_ptr(), fc.bias.data_ptr(), out.data_ptr(), batch, 1000, 2048, s()))
-    print(f"batch {batch:3d}: library {lib:6.2f} us, in-tree {own:6.2f} us (pool {pool:5.2f} + linear {lin:5.2f})", flush=True)
+    lin = graph_time(lambda: L().tca_linear_launch(feats.data_ptr(), fc.weight.data_ptr(), fc.bias.data_ptr(),
+                                                   out.data_ptr(), batch, 1000, 2048, s()))
+    print(f"batch {batch:3d}: library {lib:6.2f} us, in-tree {own:6.2f} us (pool {pool:5.2f} + linear {lin:5.2f})",
+          flush=True)

@@ -11,7 +11,8 @@ from triton_client_amd.server import spawn_server
 with spawn_server(models=["resnet50"], gpu=0) as srv:
     for level in (16, 32):
         for procs in (1, 2, 4):
-            rows = perf(["-m", "resnet50", "--urls", ",".join([srv.grpc_url] * procs), "-i", "grpc", "-b", "8", "--native",
+            rows = perf(["-m", "resnet50", "--urls", ",".join([srv.grpc_url] * procs), "-i", "grpc", "-b", "8",
+                         "--native",
                          "--shared-memory", "none", "--concurrency-range", str(level), "-p", "1000",
                          "--stability-windows", "2", "--warmup-ms", "400"])
             r = rows[0]

@@ -28,7 +28,8 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.benchmark)
     model.use_graphs = not args.no_graph
     model.fused = not args.no_fused
-    print(f"load {time.time() - t0:.1f}s graphs={model.use_graphs} fused={model.fused} benchmark={args.benchmark}", flush=True)
+    print(f"load {time.time() - t0:.1f}s graphs={model.use_graphs} fused={model.fused} benchmark={args.benchmark}",
+          flush=True)
     for b in [int(x) for x in args.batches.split(",")]:
         x = torch.randn(b, 3, 224, 224, device="cuda", dtype=torch.float16)
         out = torch.empty(b, 1000, device="cuda", dtype=torch.float32)

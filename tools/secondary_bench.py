@@ -10,7 +10,6 @@ import argparse
 import json
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -34,7 +33,8 @@ def run_configs(gpu=None, window_ms=1000, emit=None):
                      "--concurrency-range", "16"] + common)
         add("simple_http_sysshm", concurrency=16, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
             p99_us=rows[0]["p99_us"])
-        rows = perf(["-m", "simple", "-u", srv.grpc_url, "-i", "grpc", "--native", "--concurrency-range", "16"] + common)
+        rows = perf(["-m", "simple", "-u", srv.grpc_url, "-i", "grpc", "--native", "--concurrency-range",
+                     "16"] + common)
         add("simple_grpc_wire", concurrency=16, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
             p99_us=rows[0]["p99_us"])
         shm = "hip" if gpu is not None else "system"
@@ -43,7 +43,8 @@ def run_configs(gpu=None, window_ms=1000, emit=None):
                      "--concurrency-range", "16"] + where + common)
         add(f"string_grpc_{shm}shm", concurrency=16, infer_per_sec=rows[0]["infer_per_sec"], p50_us=rows[0]["p50_us"],
             p99_us=rows[0]["p99_us"])
-        rows = perf(["-m", "repeat_int32", "-u", srv.grpc_url, "-i", "grpc", "--native", "--streaming", "--shape", "IN:16",
+        rows = perf(["-m", "repeat_int32", "-u", srv.grpc_url, "-i", "grpc", "--native", "--streaming", "--shape",
+                     "IN:16",
                      "--shape", "DELAY:16", "--shape", "WAIT:1", "--concurrency-range", "16"] + common)
         add("decoupled_stream", concurrency=16, responses_per_request=16, requests_per_sec=rows[0]["requests_per_sec"],
             responses_per_sec=rows[0]["responses_per_sec"], p50_us=rows[0]["p50_us"], p99_us=rows[0]["p99_us"])

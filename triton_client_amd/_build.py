@@ -79,7 +79,8 @@ def build_pyext(force=False):
     if force or _stale(out, srcs):
         LIBDIR.mkdir(exist_ok=True)
         inc = sysconfig.get_paths()["include"]
-        _compile_atomic(["g++", *CXXFLAGS, "-I", inc, "-shared", "-o", out, *srcs, "-pthread", "-lssl", "-lcrypto", "-lz"], out)
+        _compile_atomic(["g++", *CXXFLAGS, "-I", inc, "-shared", "-o", out, *srcs, "-pthread", "-lssl", "-lcrypto",
+                         "-lz"], out)
     return out
 
 

@@ -147,7 +147,8 @@ def pyext():
         _build.build_pyext()
         from ._lib import _tca_pyext
     if not hasattr(_tca_pyext, "GrpcFront"):
-        raise ImportError("_tca_pyext was built without the gRPC front; rebuild: python -m triton_client_amd._build pyext")
+        raise ImportError("_tca_pyext was built without the gRPC front; rebuild: "
+                          "python -m triton_client_amd._build pyext")
     return _tca_pyext
 
 

@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-from .base import ExecContext, Model, ModelError, TensorSpec, register
+from .base import Model, ModelError, TensorSpec, register
 
 
 def _np_bytes(values, shape):
@@ -108,7 +108,8 @@ class _DeviceBytesPath:
         if count <= 0 or count > 4096:
             return None
         for t in ins:
-            if type(t) is not DeviceBytes or t.nbytes > limit or t.device != first.device or math.prod(t.shape) != count:
+            if (type(t) is not DeviceBytes or t.nbytes > limit or t.device != first.device
+                    or math.prod(t.shape) != count):
                 return None
         wanted = ctx.requested_outputs
         if wanted is not None and (len(wanted) != len(self.device_outputs) or set(wanted) != set(self.device_outputs)):
@@ -187,7 +188,8 @@ class _DeviceBytesPath:
                                                streams[device].handle)
                     for ((_, ins, _), callback), code, sizes in zip(items, codes, produced):
                         if code:
-                            callback(None, ModelError(f"{self.name}: {STATUS_TEXT.get(code, 'device BYTES path failed')}"))
+                            callback(None,
+                                     ModelError(f"{self.name}: {STATUS_TEXT.get(code, 'device BYTES path failed')}"))
                         else:
                             callback({name: DeviceBytesResult(ins[0].shape, size)
                                       for name, size in zip(self.device_outputs, sizes)}, None)

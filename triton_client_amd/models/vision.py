@@ -356,7 +356,8 @@ class ResNet50(Model):
         def spatial(t, layer):
             w4, bias, stride, pad = layer
             cout, cin, r, _ = w4.shape
-            pixels = t.shape[0] * ((t.shape[2] + 2 * pad - r) // stride + 1) * ((t.shape[3] + 2 * pad - r) // stride + 1)
+            pixels = (t.shape[0] * ((t.shape[2] + 2 * pad - r) // stride + 1)
+                      * ((t.shape[3] + 2 * pad - r) // stride + 1))
             if cin % 64 == 0 and conv.gemm_pays(pixels, cout, cin * r * r):
                 return conv.conv2d(t, w4, bias, None, relu=True, stride=stride, padding=pad)
             return conv.bias_act_(F.conv2d(t, w4, None, stride=stride, padding=pad), bias, None, True)
@@ -457,7 +458,8 @@ class ResNet50(Model):
         if not self.fused_expansion:
             return False
         w4, _, stride, pad = mid
-        pixels = t.shape[0] * ((t.shape[2] + 2 * pad - w4.shape[2]) // stride + 1) * ((t.shape[3] + 2 * pad - w4.shape[3]) // stride + 1)
+        pixels = (t.shape[0] * ((t.shape[2] + 2 * pad - w4.shape[2]) // stride + 1)
+                  * ((t.shape[3] + 2 * pad - w4.shape[3]) // stride + 1))
         if w4.shape[1] % 64 != 0 or c[2] != 1 or c[0].shape[0] % 64 != 0:
             return False
         if w4.shape[0] == 64:

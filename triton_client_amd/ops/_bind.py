@@ -18,7 +18,8 @@ class PreprocParams(Structure):
 
     _fields_ = [
         ("out_h", c_int), ("out_w", c_int), ("out_c", c_int), ("nhwc", c_int), ("tile_h", c_int),
-        ("max_rows", c_int), ("src_pitch", c_int), ("pad_", c_int), ("image_stride", c_longlong), ("scale", c_float * 4),
+        ("max_rows", c_int), ("src_pitch", c_int), ("pad_", c_int), ("image_stride", c_longlong),
+        ("scale", c_float * 4),
         ("bias", c_float * 4),
     ]
 
@@ -94,7 +95,8 @@ def install(lib):
     lib.tca_bytes_index_workspace_bytes.restype = c_uint64
     lib.tca_bytes_index_workspace_bytes.argtypes = [c_uint64]
     lib.tca_bytes_index_parallel_launch.restype = c_int
-    lib.tca_bytes_index_parallel_launch.argtypes = [c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+    lib.tca_bytes_index_parallel_launch.argtypes = [c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p,
                                                     c_uint64, c_void_p]
     lib.tca_bytes_gather_launch.restype = c_int
     lib.tca_bytes_gather_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p]
@@ -120,7 +122,8 @@ def install(lib):
     lib.tca_linear_launch.restype = c_int
     lib.tca_linear_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.tca_conv_pointwise_launch.restype = c_int
-    lib.tca_conv_pointwise_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+    lib.tca_conv_pointwise_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_int,
                                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.tca_conv_gemm_splitk_launch.restype = c_int
@@ -167,7 +170,8 @@ def install_rt(lib):
         lib.tca_stager_create.restype = c_int
         lib.tca_stager_create.argtypes = [c_int, c_uint64, c_int, c_uint64, POINTER(c_void_p)]
         lib.tca_stager_stage.restype = c_int
-        lib.tca_stager_stage.argtypes = [c_void_p, c_int, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64), c_void_p,
+        lib.tca_stager_stage.argtypes = [c_void_p, c_int, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64),
+                                         c_void_p,
                                          c_void_p]
         lib.tca_stager_stats.restype = c_int
         lib.tca_stager_stats.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]

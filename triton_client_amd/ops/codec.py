@@ -80,7 +80,8 @@ def bytes_index(stream_bytes, max_elems, parallel=None):
         need = int(lib().tca_bytes_index_workspace_bytes(size))
         work = torch.empty((need + 7) // 8, dtype=torch.int64, device=dev)
         rc = lib().tca_bytes_index_parallel_launch(stream_bytes.data_ptr(), size, max_elems, offsets.data_ptr(),
-                                                   lens.data_ptr(), status.data_ptr(), work.data_ptr(), work.numel() * 8,
+                                                   lens.data_ptr(), status.data_ptr(), work.data_ptr(),
+                                                   work.numel() * 8,
                                                    _stream())
         check(rc, "tca_bytes_index_parallel_launch")
     else:

@@ -208,7 +208,8 @@ def conv2d(x, weight, bias=None, residual=None, relu=False, stride=1, padding=0,
         raise ValueError("residual must match the output (fp16, channels-last)")
     if bias is not None and (bias.numel() != cout or bias.dtype != torch.float16 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous fp16 vector of Cout elements")
-    _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, cout, relu, variant, staging, split_k, tuned)
+    _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, cout, relu, variant, staging, split_k,
+            tuned)
     return out
 
 
@@ -265,14 +266,16 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     if proj_input is not None:
         if (mid != 64 or stride != 1 or residual is not None or proj_input.dtype != torch.float16
                 or tuple(proj_input.shape) != (n, 64, oh, ow) or not _is_nhwc(proj_input)):
-            raise ValueError("proj_input needs Mid = 64, stride 1, no residual and a channels-last fp16 [N, 64, OH, OW] tensor")
+            raise ValueError("proj_input needs Mid = 64, stride 1, no residual and a channels-last fp16 "
+                             "[N, 64, OH, OW] tensor")
     out3 = None
     n3 = 0
     if next_weight is not None:
         n3 = next_weight.shape[0]
         if (next_weight.dtype != torch.float16 or next_weight.numel() != n3 * cout or not next_weight.is_contiguous()
                 or n3 not in (64, 128) or (mid == 128 and n3 != 128) or not relu):
-            raise ValueError("next_weight must be a contiguous fp16 [64 | 128, Cout] matrix (128 rows with Mid = 128; relu on)")
+            raise ValueError("next_weight must be a contiguous fp16 [64 | 128, Cout] matrix (128 rows with Mid = 128; "
+                             "relu on)")
         if next_bias is not None and (next_bias.numel() != n3 or next_bias.dtype != torch.float16
                                       or not next_bias.is_contiguous()):
             raise ValueError("next_bias must be a contiguous fp16 vector of N3 elements")
@@ -383,7 +386,8 @@ def stem_conv_pool(x, packed_weight, bias, out=None):
 
     if x.dtype != torch.float16 or x.dim() != 4 or x.shape[1] != 3 or not x.is_contiguous():
         raise ValueError("x must be a contiguous NCHW fp16 tensor with 3 channels")
-    if tuple(packed_weight.shape) != (64, 192) or packed_weight.dtype != torch.float16 or not packed_weight.is_contiguous():
+    if tuple(packed_weight.shape) != (64,
+                                      192) or packed_weight.dtype != torch.float16 or not packed_weight.is_contiguous():
         raise ValueError("packed_weight must come from pack_stem_weight()")
     if bias.numel() != 64 or bias.dtype != torch.float16 or not bias.is_contiguous():
         raise ValueError("bias must be a contiguous fp16 vector of 64 elements")
@@ -396,7 +400,8 @@ def stem_conv_pool(x, packed_weight, bias, out=None):
         out = torch.empty((n, 64, ph, pw), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
     elif tuple(out.shape) != (n, 64, ph, pw) or out.dtype != torch.float16 or not _is_nhwc(out):
         raise ValueError("out must be a channels-last fp16 tensor of the pooled shape")
-    rc = lib().tca_stem_conv_pool_launch(x.data_ptr(), packed_weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w,
+    rc = lib().tca_stem_conv_pool_launch(x.data_ptr(), packed_weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n,
+                                         h, w,
                                          _stream())
     check(rc, "tca_stem_conv_pool_launch")
     return out

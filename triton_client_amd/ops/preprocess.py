@@ -256,7 +256,8 @@ class Preprocessor:
         L = lib()
         self._sync_tables()
         check(L.tca_hip_memcpy_async(self._dev_src.ptr, batch.pinned.ptr, batch.nbytes, 1, sh), "image upload")
-        check(L.tca_hip_memcpy_async(self._desc_dev.ptr, ctypes.addressof(batch.desc), ctypes.sizeof(batch.desc), 1, sh),
+        check(L.tca_hip_memcpy_async(self._desc_dev.ptr, ctypes.addressof(batch.desc), ctypes.sizeof(batch.desc), 1,
+                                     sh),
               "descriptor upload")
         rc = L.tca_preprocess_launch(self._desc_dev.ptr, self._bounds_dev.ptr, self._coeffs_dev.ptr,
                                      as_pointer(out, out_offset), ctypes.byref(batch.params), batch.count,

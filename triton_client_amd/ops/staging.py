@@ -16,9 +16,11 @@ class WireStager:
     def __init__(self, device, entry_bytes, dev_bytes, entries=4):
         self._lib = lib()
         if not hasattr(self._lib, "tca_stager_create"):
-            raise RuntimeError("libtca_hip.so was built without the wire stager; run `python -m triton_client_amd._build hip`")
+            raise RuntimeError("libtca_hip.so was built without the wire stager; run "
+                               "`python -m triton_client_amd._build hip`")
         handle = ctypes.c_void_p()
-        rc = self._lib.tca_stager_create(int(device), int(entry_bytes), int(entries), int(dev_bytes), ctypes.byref(handle))
+        rc = self._lib.tca_stager_create(int(device), int(entry_bytes), int(entries), int(dev_bytes),
+                                         ctypes.byref(handle))
         if rc != 0:
             raise RuntimeError(f"tca_stager_create failed ({rc}): {self._lib.tca_stager_error().decode()}")
         self._handle = handle

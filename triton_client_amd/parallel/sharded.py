@@ -739,7 +739,8 @@ def main(argv=None):
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--device", type=int, required=True)
     ap.add_argument("--address", required=True)
-    ap.add_argument("--model", default="resnet50", help="zoo model, or the stand-ins 'test_rowsum' (tests) / 'test_noop' (transport benchmark)")
+    ap.add_argument("--model", default="resnet50",
+                    help="zoo model, or the stand-ins 'test_rowsum' (tests) / 'test_noop' (transport benchmark)")
     ap.add_argument("--warm-rows", default="")
     ap.add_argument("--shard-rows", type=int, default=int(os.environ.get("TCA_SHARD_ROWS", "128")))
     ap.add_argument("--sample-shape", default="3,224,224")

@@ -27,8 +27,10 @@ def main(argv=None):
                     help="gRPC front: native C++ HTTP/2 reactors (default) or the stock Python gRPC server")
     ap.add_argument("--http-impl", choices=["native", "asyncio"], default=None,
                     help="HTTP front: C++ reactors (default) or the pure-Python asyncio one")
-    ap.add_argument("--http-reactors", type=int, default=None, help="epoll threads of the native HTTP front (default 2)")
-    ap.add_argument("--grpc-reactors", type=int, default=None, help="epoll threads of the native gRPC front (default 2)")
+    ap.add_argument("--http-reactors", type=int, default=None,
+                    help="epoll threads of the native HTTP front (default 2)")
+    ap.add_argument("--grpc-reactors", type=int, default=None,
+                    help="epoll threads of the native gRPC front (default 2)")
     ap.add_argument("--tls-cert", default=None, help="PEM certificate chain: serve HTTPS / gRPC over TLS")
     ap.add_argument("--tls-key", default=None, help="PEM private key of --tls-cert")
     ap.add_argument("--tls-client-ca", default=None, help="PEM CA bundle: require client certificates signed by it")
@@ -48,7 +50,8 @@ def main(argv=None):
         sys.setswitchinterval(float(os.environ["TCA_SWITCH_INTERVAL_US"]) * 1e-6)
     server = Server(models=models, gpu=args.gpu, http_port=args.http_port, grpc_port=args.grpc_port, host=args.host,
                     model_control=args.model_control_mode, http_workers=args.http_workers,
-                    grpc_workers=args.grpc_workers, grpc_impl=args.grpc_impl, grpc_reactors=args.grpc_reactors, http_impl=args.http_impl,
+                    grpc_workers=args.grpc_workers, grpc_impl=args.grpc_impl, grpc_reactors=args.grpc_reactors,
+                    http_impl=args.http_impl,
                     http_reactors=args.http_reactors, tls_cert=args.tls_cert,
                     tls_key=args.tls_key, tls_client_ca=args.tls_client_ca).start()
     if args.announce:

@@ -95,7 +95,8 @@ class DynamicBatcher:
         # GPU waits up to `burst_window_s` for the rest of the burst; serial traffic (one
         # request at a time, gaps of a whole round trip) never waits.
         self.burst_gap_s = float(os.environ.get("TCA_BURST_GAP_US", getattr(self.model, "burst_gap_us", 300))) / 1e6
-        self.burst_window_s = float(os.environ.get("TCA_BURST_WINDOW_US", getattr(self.model, "burst_window_us", 100))) / 1e6
+        self.burst_window_s = float(os.environ.get("TCA_BURST_WINDOW_US", getattr(self.model, "burst_window_us",
+                                                                                  100))) / 1e6
         self._last_arrival_ns = 0
         self._last_done = (0, 1)  # (time, requests) of the batch that completed last
         # Execution instances of the model (own HIP stream + own captured graphs each):

@@ -309,7 +309,8 @@ class SystemShmRegistry(_Leased):
             self._regions[name] = _SystemRegion(key, offset, byte_size, handle)
         if self.native is not None:
             try:
-                self.native.register_region(name, key if key.startswith("/") else "/" + key, int(offset), int(byte_size))
+                self.native.register_region(name, key if key.startswith("/") else "/" + key, int(offset),
+                                            int(byte_size))
             except ValueError:
                 pass  # requests naming this region take the general path
 
@@ -930,7 +931,8 @@ class InferenceCore:
         if (t.datatype == "BYTES" and getattr(model, "device_bytes", False) and not mapping.host_backed
                 and ref.byte_size > 0):
             # the model can walk the stream on the GPU: hand over the range, not a host copy
-            return _device_bytes_class()(mapping.address + ref.offset, ref.byte_size, shape, mapping, ref.offset, device_id)
+            return _device_bytes_class()(mapping.address + ref.offset, ref.byte_size, shape, mapping, ref.offset,
+                                         device_id)
         deferred.append((t, shape, mapping, ref))  # read together with the request's other ranges
         return None
 

@@ -13,7 +13,6 @@ from concurrent import futures
 
 import grpc
 
-from ..grpc import model_config_pb2 as mc
 from ..grpc import service_pb2 as pb
 from ..grpc import service_pb2_grpc
 from .core import InferRequest, InputTensor, RequestedOutput, ServerError, ShmRef, encode_wire

@@ -152,7 +152,8 @@ class NativeGrpcFront:
     def _infer(self, call, req):
         def done(resp, err):
             if err is not None:
-                self._front.finish(call, _STATUS.get(getattr(err, "code", 500), _INTERNAL), str(getattr(err, "message", err)))
+                self._front.finish(call, _STATUS.get(getattr(err, "code", 500), _INTERNAL),
+                                   str(getattr(err, "message", err)))
             else:
                 self._front.reply(call, response_to_proto(resp).SerializeToString())
 

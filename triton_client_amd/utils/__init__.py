@@ -176,7 +176,8 @@ def serialized_byte_size(tensor_value):
     if tensor_value.size == 0:
         return 0
     total = 0
-    for item in tensor_value.reshape(-1).tolist() if tensor_value.flags.c_contiguous else tensor_value.flatten().tolist():
+    flat = tensor_value.reshape(-1) if tensor_value.flags.c_contiguous else tensor_value.flatten()
+    for item in flat.tolist():
         total += len(item)
     return total
 

@@ -268,7 +268,8 @@ def _read_bytes_elements(shm_handle, count, offset):
     items, pos = [], 0
     chunk = _WALK_CHUNK
     while len(items) < count:
-        if pos + 4 > len(have) or (pos + 4 <= len(have) and pos + 4 + int.from_bytes(have[pos: pos + 4].tobytes(), "little") > len(have)):
+        if pos + 4 > len(have) or (pos + 4 <= len(have) and pos + 4 + int.from_bytes(have[pos: pos + 4].tobytes(),
+                                                                                     "little") > len(have)):
             want = pos + 4 if pos + 4 > len(have) else pos + 4 + int.from_bytes(have[pos: pos + 4].tobytes(), "little")
             if want > size:
                 raise ValueError("stream runs past the region")

@@ -53,7 +53,8 @@ class _AliasFinder(importlib.abc.MetaPathFinder):
             return None
         if real_spec is None:
             return None
-        spec = importlib.util.spec_from_loader(fullname, _AliasLoader(real), is_package=real_spec.submodule_search_locations is not None)
+        spec = importlib.util.spec_from_loader(fullname, _AliasLoader(real),
+                                               is_package=real_spec.submodule_search_locations is not None)
         return spec
 
 

@@ -5,7 +5,8 @@ import warnings
 
 warnings.simplefilter("always", DeprecationWarning)
 warnings.warn(
-    "The package `tritonhttpclient` is deprecated and will be removed in a future version. Please use instead `tritonclient.http`",
+    "The package `tritonhttpclient` is deprecated and will be removed in a future version. "
+    "Please use instead `tritonclient.http`",
     DeprecationWarning,
 )
 
