@@ -661,10 +661,15 @@ class ShardWorker:
             return
         import torch
 
+        # Grouped calls like the root's: on the NCCL backend a grouped point-to-point operation runs on
+        # the group's communicator while a plain send / recv creates one per pair of ranks - the two
+        # forms never meet each other.  wait() makes this stream wait, not the host.
         with torch.cuda.stream(self.streams[slot]):
-            dist.recv(x, src=0)
+            for work in dist.batch_isend_irecv([dist.P2POp(dist.irecv, x, 0)]):
+                work.wait()
             self.forward(x, out, slot)
-            dist.send(out, dst=0)
+            for work in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, 0)]):
+                work.wait()
 
     def close(self):
         for lane in getattr(self, "lanes", ()):
