@@ -326,8 +326,11 @@ class ShardRoot:
         for rank in range(1, self.world):
             conn, info = hello[rank]
             self._conns.append(conn)
+            # opened on THIS process's GPU: the mapping (and the lazily enabled peer access) is for the
+            # device whose kernels store into the inbox, the exporter's ordinal travels inside the handle
             self._peer_inbox.append(hipshm.open_shared_memory_region(
-                f"{self.tag}_inbox{rank}", info["inbox"], info["inbox_bytes"], info["device"]))
+                f"{self.tag}_inbox{rank}", info["inbox"], info["inbox_bytes"],
+                info["device"] if self.fake else self.device))
             conn.send({"control_key": self.control.key, "workers": self.workers, "world": self.world,
                        "flags": self.flags.region._raw, "flags_bytes": self.flags.nbytes,
                        "gather": self.gather._raw, "gather_bytes": self.gather.byte_size, "gather_device": self.device,
@@ -536,10 +539,12 @@ class ShardWorker:
         self.sample_bytes, self.out_row_bytes = cfg["sample_bytes"], cfg["out_row_bytes"]
         self.mode = cfg["mode"]
         self.control = ControlBlock(cfg["control_key"], cfg["workers"], create=False)
+        # the root's flag block and gather buffer, mapped for THIS replica's GPU (its kernels poll and store)
+        own = cfg["gather_device"] if self.fake else self.device
         self.flags = FlagBlock(hipshm, cfg["workers"], opened=hipshm.open_shared_memory_region(
-            f"tca_shard_flags_{os.getpid()}", cfg["flags"], cfg["flags_bytes"], cfg["gather_device"]))
+            f"tca_shard_flags_{os.getpid()}", cfg["flags"], cfg["flags_bytes"], own))
         self.gather = hipshm.open_shared_memory_region(f"tca_shard_gather_{os.getpid()}", cfg["gather"],
-                                                       cfg["gather_bytes"], cfg["gather_device"])
+                                                       cfg["gather_bytes"], own)
         if not self.fake:
             import torch
 
