@@ -69,6 +69,7 @@ struct HttpServerFront::Reactor {
     std::string rbuf;  // bytes received and not consumed yet
     Request req;
     size_t body_left = 0;  // BODY: bytes still missing; CHUNK_DATA: bytes left of the current chunk
+    size_t body_filled = 0;  // BODY: bytes of the (pre-sized) body received so far
     bool continued = false;
     std::deque<std::string> out;  // response bytes not sent yet
     size_t out_off = 0;           // bytes of out.front() already sent
@@ -202,14 +203,14 @@ struct HttpServerFront::Reactor {
           break;
         }
         case Phase::BODY: {
+          // the body was sized from Content-Length when the head was parsed
           const size_t take = std::min(c->body_left, c->rbuf.size());
-          if (take == c->rbuf.size() && c->req.body.empty() && take == c->body_left) {
-            c->req.body.swap(c->rbuf);  // the whole body arrived with the head: no copy
-          } else {
-            c->req.body.append(c->rbuf, 0, take);
+          if (take) {
+            std::memcpy(&c->req.body[c->body_filled], c->rbuf.data(), take);
             c->rbuf.erase(0, take);
+            c->body_filled += take;
+            c->body_left -= take;
           }
-          c->body_left -= take;
           if (c->body_left) return;
           Dispatch(c);
           return;
@@ -324,11 +325,13 @@ struct HttpServerFront::Reactor {
         return false;
       }
       c->body_left = static_cast<size_t>(length);
-      r.body.reserve(c->body_left);
+      c->body_filled = 0;
+      r.body.resize(c->body_left);  // received in place: from the head's tail by memcpy, then straight from the socket
       c->phase = Phase::BODY;
     } else {
       c->phase = Phase::BODY;
       c->body_left = 0;
+      c->body_filled = 0;
     }
     // the client waits for the go-ahead only when it has not sent the body along
     const size_t have = b.size() - (end + 4);
@@ -455,11 +458,9 @@ struct HttpServerFront::Reactor {
         }
       } else if (c->phase == Phase::BODY && c->rbuf.empty() && c->body_left >= 65536) {
         // a large body: receive straight into the request's buffer, no bounce through `buf`
-        const size_t have = c->req.body.size();
-        c->req.body.resize(have + c->body_left);
-        n = recv(c->fd, &c->req.body[have], c->body_left, 0);
-        c->req.body.resize(have + (n > 0 ? static_cast<size_t>(n) : 0));
+        n = recv(c->fd, &c->req.body[c->body_filled], c->body_left, 0);
         if (n > 0) {
+          c->body_filled += static_cast<size_t>(n);
           c->body_left -= static_cast<size_t>(n);
           if (c->body_left == 0) {
             Dispatch(c);
