@@ -263,6 +263,13 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
     WithGil(self, [self, call, method, req] { DeliverUnary(self, call, method, *req); });
   };
   h.on_stream_message = [self](uint64_t call, const std::string& method, std::string&& request) {
+    if (self->native != nullptr && method == "ModelStreamInfer") {
+      std::vector<std::string> responses;
+      if ((*self->native)->TryGrpcStream(request, &responses)) {  // answered here, in order, no interpreter
+        for (auto& m : responses) self->front->Send(call, std::move(m));
+        return;
+      }
+    }
     auto req = std::make_shared<std::string>(std::move(request));
     WithGil(self, [self, call, method, req] {
       CallPython(self->on_stream_message, "(Ksy#)", static_cast<unsigned long long>(call), method.c_str(), req->data(),

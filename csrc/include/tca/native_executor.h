@@ -11,8 +11,9 @@
 //
 // Kernels: "add_sub" (OUTPUT0 = INPUT0 + INPUT1, OUTPUT1 = INPUT0 - INPUT1, any integer
 // or floating type; the `simple` model family the reference's examples and perf tools
-// are written against, e.g. `src/c++/examples/simple_http_infer_client.cc:127-160`) and
-// "identity" (OUTPUT0 = INPUT0).
+// are written against, e.g. `src/c++/examples/simple_http_infer_client.cc:127-160`),
+// "identity" (OUTPUT0 = INPUT0) and, over gRPC streams, the decoupled "repeat" (one
+// response per input element, as `src/python/examples/simple_grpc_custom_repeat.py` uses).
 //
 // Statistics are accumulated here and collected by the Python core (TakeStats), so the
 // model statistics endpoints keep counting requests that never reached Python.
@@ -63,6 +64,10 @@ class NativeExecutor {
 
   // `request` = serialized ModelInferRequest; true: `response` holds the serialized ModelInferResponse.
   bool TryGrpc(const std::string& request, std::string* response);
+  // One message of a ModelStreamInfer call; true: `responses` holds the serialized ModelStreamInferResponse
+  // messages to send, in order (one for the ordinary kernels, one per element - plus the empty final one
+  // when the request asks for it - for the decoupled "repeat" kernel).
+  bool TryGrpcStream(const std::string& request, std::vector<std::string>* responses);
   // `body` = JSON header (+ binary tensors when `header_length` >= 0); true: answer in headers / parts.
   bool TryHttp(const std::string& model, const std::string& version, const std::string& body, int64_t header_length,
                HeaderList* headers, std::vector<std::string>* parts);
@@ -88,7 +93,12 @@ class NativeExecutor {
     Stats stats;
   };
   struct Request;
+  struct Result;
+  static void BuildGrpcResponse(const Request& req, const std::vector<Result>& results, int final_flag,
+                                std::string* response);
   bool Run(Request* req, const std::shared_ptr<Model>& model);
+  bool RunRepeat(Request* req, const std::shared_ptr<Model>& model, std::vector<std::string>* responses);
+  bool ParseGrpc(const std::string& request, bool stream, Request* out, std::shared_ptr<Model>* model);
   std::shared_ptr<Model> FindModel(const std::string& name, const std::string& version);
 
   std::atomic<bool> enabled_{true};

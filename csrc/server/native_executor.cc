@@ -16,7 +16,7 @@ namespace tca {
 namespace server {
 namespace {
 
-enum Kernel { kAddSub = 1, kIdentity = 2 };
+enum Kernel { kAddSub = 1, kIdentity = 2, kRepeat = 3 };
 
 size_t ItemSize(const std::string& dt) {
   if (dt == "INT8" || dt == "UINT8" || dt == "BOOL") return 1;
@@ -68,6 +68,14 @@ struct ShmRef {
 
 }  // namespace
 
+struct NativeExecutor::Result {
+  std::string name, datatype;
+  std::vector<int64_t> shape;
+  std::string bytes;  // when not in shared memory
+  ShmRef shm;
+  size_t shm_bytes = 0;
+};
+
 struct NativeExecutor::Request {
   struct Input {
     std::string name, datatype;
@@ -83,16 +91,9 @@ struct NativeExecutor::Request {
     bool binary = true;  // HTTP only
   };
   std::string model, version, id;
+  bool want_final = false;  // streams: triton_enable_empty_final_response
   std::vector<Input> inputs;
   std::vector<Output> outputs;  // empty = all
-  // results
-  struct Result {
-    std::string name, datatype;
-    std::vector<int64_t> shape;
-    std::string bytes;  // when not in shared memory
-    ShmRef shm;
-    size_t shm_bytes = 0;
-  };
   std::vector<Result> results;
   std::string version_used;
   std::vector<std::shared_ptr<Region>> held;  // regions in use stay mapped until the answer is built
@@ -112,6 +113,14 @@ Error NativeExecutor::SetModel(const ModelSpec& spec) {
   } else if (spec.kernel == "identity") {
     if (spec.inputs.size() != 1 || spec.outputs.size() != 1) return Error("identity needs one input and one output");
     m->kernel = kIdentity;
+  } else if (spec.kernel == "repeat") {
+    // decoupled: IN INT32[-1], DELAY UINT32[-1], WAIT UINT32[1] -> one response (OUT INT32[1], IDX UINT32[1]) per element
+    if (spec.max_batch != 0 || spec.inputs.size() != 3 || spec.outputs.size() != 2) return Error("repeat needs IN, DELAY, WAIT and OUT, IDX");
+    m->kernel = kRepeat;
+    m->itemsize = 4;
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    models_[spec.name] = std::move(m);
+    return Error::Success();
   } else {
     return Error("unknown native kernel '" + spec.kernel + "'");
   }
@@ -252,7 +261,7 @@ bool NativeExecutor::Run(Request* req, const std::shared_ptr<Model>& model) {
     for (size_t k = 0; k < spec.outputs.size(); ++k)
       if (spec.outputs[k].name == o.name) slot = k;
     if (slot == spec.outputs.size() || dest[slot] != nullptr) return false;
-    Request::Result r;
+    Result r;
     r.name = o.name;
     r.datatype = spec.outputs[slot].datatype;
     r.shape = ordered[0]->shape;
@@ -360,9 +369,10 @@ bool ShmParam(const uint8_t* d, size_t n, ShmRef* shm, bool* other) {
 
 }  // namespace
 
-bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) {
-  if (!enabled_.load(std::memory_order_relaxed)) return false;
-  Request req;
+// Decodes a ModelInferRequest.  `stream`: the request came over ModelStreamInfer, where the one request
+// parameter a streaming client commonly sets (triton_enable_empty_final_response) is understood.
+bool NativeExecutor::ParseGrpc(const std::string& request, bool stream, Request* out, std::shared_ptr<Model>* model_out) {
+  Request& req = *out;
   req.t_arrive = NowNs();
   std::vector<std::pair<const uint8_t*, size_t>> raws;
   pb::Reader r(request);
@@ -377,6 +387,38 @@ bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) 
       if (!r.String(&req.version)) return false;
     } else if (f == 3 && wt == pb::kLen) {
       if (!r.String(&req.id)) return false;
+    } else if (f == 4 && wt == pb::kLen && stream) {
+      // map<string, InferParameter> entry: only the final-response switch (a bool) is ours
+      const uint8_t* d;
+      size_t n;
+      if (!r.Len(&d, &n)) return false;
+      pb::Reader e(d, n);
+      std::string key;
+      const uint8_t* vd = nullptr;
+      size_t vn = 0;
+      uint32_t ef, ewt;
+      while (e.Next(&ef, &ewt)) {
+        if (ef == 1 && ewt == pb::kLen) {
+          if (!e.String(&key)) return false;
+        } else if (ef == 2 && ewt == pb::kLen) {
+          if (!e.Len(&vd, &vn)) return false;
+        } else if (!e.Skip(ewt)) {
+          return false;
+        }
+      }
+      if (e.Failed() || key != "triton_enable_empty_final_response") return false;
+      pb::Reader p(vd, vn);
+      bool seen = false;
+      while (p.Next(&ef, &ewt)) {
+        uint64_t u;
+        if (ef == 1 && ewt == pb::kVarint && p.Varint(&u)) {
+          req.want_final = u != 0;
+          seen = true;
+        } else {
+          return false;
+        }
+      }
+      if (p.Failed() || (!seen && vn != 0)) return false;
     } else if (f == 4) {
       return false;  // request parameters (sequences, priorities, timeouts...): general path
     } else if (f == 5 && wt == pb::kLen) {
@@ -395,10 +437,10 @@ bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) 
           const uint8_t* sd;
           size_t sn;
           if (!t.Len(&sd, &sn)) return false;
-          pb::Reader s(sd, sn);
-          while (!s.Done()) {
+          pb::Reader sr(sd, sn);
+          while (!sr.Done()) {
             uint64_t v;
-            if (!s.Varint(&v)) return false;
+            if (!sr.Varint(&v)) return false;
             in.shape.push_back(static_cast<int64_t>(v));
           }
         } else if (tf == 3 && twt == pb::kVarint) {
@@ -419,22 +461,22 @@ bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) 
       const uint8_t* d;
       size_t n;
       if (!r.Len(&d, &n)) return false;
-      Request::Output out;
+      Request::Output o;
       pb::Reader t(d, n);
       uint32_t tf, twt;
       while (t.Next(&tf, &twt)) {
         if (tf == 1 && twt == pb::kLen) {
-          if (!t.String(&out.name)) return false;
+          if (!t.String(&o.name)) return false;
         } else if (tf == 2 && twt == pb::kLen) {
           const uint8_t* pd;
           size_t pn;
-          if (!t.Len(&pd, &pn) || !ShmParam(pd, pn, &out.shm, &other)) return false;
+          if (!t.Len(&pd, &pn) || !ShmParam(pd, pn, &o.shm, &other)) return false;
         } else {
           return false;
         }
       }
       if (t.Failed() || other) return false;
-      req.outputs.push_back(std::move(out));
+      req.outputs.push_back(std::move(o));
     } else if (f == 7 && wt == pb::kLen) {
       const uint8_t* d;
       size_t n;
@@ -458,19 +500,35 @@ bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) 
     ++next_raw;
   }
   if (next_raw != raws.size()) return false;
-  if (!Run(&req, model)) {
-    declined_.fetch_add(1, std::memory_order_relaxed);
-    return false;
-  }
-  const uint64_t t2 = NowNs();
+  *model_out = std::move(model);
+  return true;
+}
+
+namespace {
+
+void BoolParam(pb::Writer* w, uint32_t field, const char* key, bool value) {
+  std::string entry, body;
+  pb::Writer ew(&entry), vw(&body);
+  vw.Bool(1, value);
+  ew.String(1, key);
+  ew.Message(2, body);
+  w->Message(field, entry);
+}
+
+}  // namespace
+
+// ModelInferResponse of the results in `req`; `final_flag`: -1 none, 0 / 1 = triton_final_response parameter.
+void NativeExecutor::BuildGrpcResponse(const Request& req, const std::vector<Result>& results, int final_flag,
+                                       std::string* response) {
   response->clear();
   response->reserve(256);
   pb::Writer w(response);
   w.String(1, req.model);
   w.String(2, req.version_used);
   if (!req.id.empty()) w.String(3, req.id);
+  if (final_flag >= 0) BoolParam(&w, 4, "triton_final_response", final_flag != 0);
   std::string scratch, entry, value;
-  for (const auto& res : req.results) {
+  for (const auto& res : results) {
     scratch.clear();
     pb::Writer t(&scratch);
     t.String(1, res.name);
@@ -496,8 +554,22 @@ bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) 
     }
     w.Message(5, scratch);
   }
-  for (const auto& res : req.results)
+  for (const auto& res : results)
     if (!res.shm.set) w.Bytes(6, res.bytes.data(), res.bytes.size());
+}
+
+bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) {
+  if (!enabled_.load(std::memory_order_relaxed)) return false;
+  Request req;
+  std::shared_ptr<Model> model;
+  if (!ParseGrpc(request, false, &req, &model)) return false;
+  if (model->kernel == kRepeat) return false;  // decoupled: streams only (the general path words the refusal)
+  if (!Run(&req, model)) {
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return false;
+  }
+  const uint64_t t2 = NowNs();
+  BuildGrpcResponse(req, req.results, -1, response);
   {
     int batch = 1;
     if (model->spec.max_batch > 0 && !req.results.empty() && !req.results[0].shape.empty())
@@ -505,6 +577,113 @@ bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) 
     std::lock_guard<std::mutex> lk(model->stats_mu);
     model->stats.by_batch[batch].output_ns += NowNs() - t2;
   }
+  handled_.fetch_add(1, std::memory_order_relaxed);
+  return true;
+}
+
+// The decoupled kernel: IN[n], DELAY[n] (all zero here), WAIT[1] (zero) -> n responses OUT = [IN[i]], IDX = [i].
+bool NativeExecutor::RunRepeat(Request* req, const std::shared_ptr<Model>& model, std::vector<std::string>* responses) {
+  const Request::Input *in = nullptr, *delay = nullptr, *wait = nullptr;
+  for (const auto& t : req->inputs) {
+    const Request::Input** slot = t.name == "IN" ? &in : t.name == "DELAY" ? &delay : t.name == "WAIT" ? &wait : nullptr;
+    if (slot == nullptr || *slot != nullptr || t.shm.set || !t.has_data || t.shape.size() != 1 || t.shape[0] < 0) return false;
+    *slot = &t;
+  }
+  if (in == nullptr || delay == nullptr || wait == nullptr) return false;
+  if (in->datatype != "INT32" || delay->datatype != "UINT32" || wait->datatype != "UINT32") return false;
+  const size_t n = static_cast<size_t>(in->shape[0]);
+  if (n > (1u << 20) || delay->shape[0] != in->shape[0] || wait->shape[0] != 1) return false;
+  if (in->size != 4 * n || delay->size != 4 * n || wait->size != 4) return false;
+  for (size_t i = 0; i < delay->size; ++i)
+    if (delay->data[i] != 0) return false;  // a response that has to wait belongs on a thread that may sleep
+  for (size_t i = 0; i < 4; ++i)
+    if (wait->data[i] != 0) return false;
+  bool want_out = req->outputs.empty(), want_idx = req->outputs.empty();
+  for (const auto& o : req->outputs) {
+    if (o.shm.set) return false;
+    if (o.name == "OUT" && !want_out) want_out = true;
+    else if (o.name == "IDX" && !want_idx) want_idx = true;
+    else return false;
+  }
+  req->version_used = model->spec.version;
+  const uint64_t t0 = NowNs();
+  responses->clear();
+  responses->reserve(n + 1);
+  std::vector<Result> results;
+  std::string inner;
+  for (size_t i = 0; i < n; ++i) {
+    results.clear();
+    if (want_out) {
+      Result r;
+      r.name = "OUT";
+      r.datatype = "INT32";
+      r.shape = {1};
+      r.bytes.assign(reinterpret_cast<const char*>(in->data) + 4 * i, 4);
+      results.push_back(std::move(r));
+    }
+    if (want_idx) {
+      Result r;
+      r.name = "IDX";
+      r.datatype = "UINT32";
+      r.shape = {1};
+      const uint32_t idx = static_cast<uint32_t>(i);
+      r.bytes.assign(reinterpret_cast<const char*>(&idx), 4);
+      results.push_back(std::move(r));
+    }
+    BuildGrpcResponse(*req, results, req->want_final ? 0 : -1, &inner);
+    std::string wrapped;
+    pb::Writer w(&wrapped);
+    w.Message(2, inner);  // ModelStreamInferResponse.infer_response
+    responses->push_back(std::move(wrapped));
+  }
+  if (req->want_final) {
+    results.clear();
+    BuildGrpcResponse(*req, results, 1, &inner);
+    std::string wrapped;
+    pb::Writer w(&wrapped);
+    w.Message(2, inner);
+    responses->push_back(std::move(wrapped));
+  }
+  {
+    std::lock_guard<std::mutex> lk(model->stats_mu);
+    Stats& s = model->stats;
+    ++s.requests;
+    ++s.inferences;
+    s.last_ms = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::milliseconds>(
+                                          std::chrono::system_clock::now().time_since_epoch()).count());
+    BatchStats& bs = s.by_batch[1];
+    ++bs.count;
+    bs.infer_ns += NowNs() - t0;
+    s.queue_ns += t0 - req->t_arrive;
+  }
+  return true;
+}
+
+bool NativeExecutor::TryGrpcStream(const std::string& request, std::vector<std::string>* responses) {
+  if (!enabled_.load(std::memory_order_relaxed)) return false;
+  Request req;
+  std::shared_ptr<Model> model;
+  if (!ParseGrpc(request, true, &req, &model)) return false;
+  if (model->kernel == kRepeat) {
+    if (!RunRepeat(&req, model, responses)) {
+      declined_.fetch_add(1, std::memory_order_relaxed);
+      return false;
+    }
+    handled_.fetch_add(1, std::memory_order_relaxed);
+    return true;
+  }
+  if (!Run(&req, model)) {
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return false;
+  }
+  std::string inner;
+  // a one-response model answers a stream with its response marked final when the marker was asked for
+  BuildGrpcResponse(req, req.results, req.want_final ? 1 : -1, &inner);
+  std::string wrapped;
+  pb::Writer w(&wrapped);
+  w.Message(2, inner);
+  responses->clear();
+  responses->push_back(std::move(wrapped));
   handled_.fetch_add(1, std::memory_order_relaxed);
   return true;
 }

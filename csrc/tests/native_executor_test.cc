@@ -212,6 +212,54 @@ int main() {
   if (!ex.TryGrpc(GrpcRequest(a, b, 1, false), &response)) Fail("final request declined");
   NativeExecutor::Stats st;
   if (!ex.TakeStats("simple", &st) || st.requests != 1 || st.by_batch[1].count != 1) Fail("final statistics");
+  // streams: an ordinary kernel answers with one wrapped response, the decoupled kernel with one per element
+  {
+    std::vector<std::string> stream;
+    if (!ex.TryGrpcStream(GrpcRequest(a, b, 1, false), &stream) || stream.size() != 1) Fail("stream: simple");
+    NativeExecutor::ModelSpec rep;
+    rep.name = "repeat_int32";
+    rep.version = "1";
+    rep.kernel = "repeat";
+    rep.inputs = {{"IN", "INT32", {-1}}, {"DELAY", "UINT32", {-1}}, {"WAIT", "UINT32", {1}}};
+    rep.outputs = {{"OUT", "INT32", {1}}, {"IDX", "UINT32", {1}}};
+    if (!ex.SetModel(rep).IsOk()) Fail("registering the decoupled kernel");
+    auto repeat_request = [&](uint32_t delay_of_second) {
+      std::string out;
+      pb::Writer w(&out);
+      w.String(1, "repeat_int32");
+      w.String(3, "r");
+      std::string entry, value;
+      pb::Writer ew(&entry), vw(&value);
+      vw.Bool(1, true);
+      ew.String(1, "triton_enable_empty_final_response");
+      ew.Message(2, value);
+      w.Message(4, entry);
+      const int32_t in[3] = {5, 6, 7};
+      const uint32_t delay[3] = {0, delay_of_second, 0}, wait[1] = {0};
+      const char* names[3] = {"IN", "DELAY", "WAIT"};
+      const char* types[3] = {"INT32", "UINT32", "UINT32"};
+      const uint64_t counts[3] = {3, 3, 1};
+      for (int k = 0; k < 3; ++k) {
+        std::string t, shape;
+        pb::Writer tw(&t), sw(&shape);
+        tw.String(1, names[k]);
+        tw.String(2, types[k]);
+        sw.Varint(counts[k]);
+        tw.Message(3, shape);
+        w.Message(5, t);
+      }
+      w.Bytes(7, in, 12);
+      w.Bytes(7, delay, 12);
+      w.Bytes(7, wait, 4);
+      return out;
+    };
+    if (!ex.TryGrpcStream(repeat_request(0), &stream) || stream.size() != 4) Fail("stream: repeat with final marker");
+    if (ex.TryGrpcStream(repeat_request(3), &stream)) Fail("stream: a delayed response was taken natively");
+    std::string unary;
+    if (ex.TryGrpc(repeat_request(0), &unary)) Fail("unary call on the decoupled kernel accepted");
+    const std::string full = repeat_request(0);
+    for (size_t cut = 0; cut < full.size(); cut += 2) ex.TryGrpcStream(full.substr(0, cut), &stream);
+  }
   // malformed input must be declined, not crash
   for (size_t cut = 0; cut < response.size(); cut += 3) {
     std::string junk = GrpcRequest(a, b, 1, false).substr(0, cut);

@@ -15,7 +15,7 @@ from tritonclient.utils import InferenceServerException
 def servers():
     from triton_client_amd.server import Server
 
-    models = ["simple", "simple_int8", "simple_string", "custom_identity_int32"]
+    models = ["simple", "simple_int8", "simple_string", "custom_identity_int32", "repeat_int32"]
     on = Server(models=models, native_exec=True, model_control="explicit").start()
     off = Server(models=models, native_exec=False, model_control="explicit").start()
     for srv in (on, off):
@@ -209,3 +209,103 @@ def test_statistics_count_native_requests_and_unload_stops_the_path(servers):
         np.testing.assert_array_equal(c.infer("simple", _inputs(grpcclient, a, b)).as_numpy("OUTPUT0"), a + b)
         assert _handled(on) == before
         c.load_model("simple")
+
+
+def _stream_collect(url, send, expected):
+    """Opens a stream, runs ``send(client)``, returns the first ``expected`` (result, error) pairs."""
+    import queue
+
+    done = queue.Queue()
+    got = []
+    with grpcclient.InferenceServerClient(url) as c:
+        c.start_stream(lambda result, error: done.put((result, error)))
+        send(c)
+        for _ in range(expected):
+            got.append(done.get(timeout=20))
+        c.stop_stream()
+    return got
+
+
+@pytest.mark.parametrize("final", [False, True])
+def test_decoupled_stream_runs_natively_and_matches(servers, final):
+    on, off = servers
+    for srv in (on, off):
+        with httpclient.InferenceServerClient(srv.http_url) as c:
+            c.load_model("repeat_int32")
+    values = np.array([7, -3, 2**31 - 1, 0, 42], dtype=np.int32)
+
+    def send(c, delays=None, outputs=None):
+        n = len(values)
+        c.async_stream_infer("repeat_int32", [
+            grpcclient.InferInput("IN", [n], "INT32").set_data_from_numpy(values),
+            grpcclient.InferInput("DELAY", [n], "UINT32").set_data_from_numpy(
+                np.zeros(n, dtype=np.uint32) if delays is None else delays),
+            grpcclient.InferInput("WAIT", [1], "UINT32").set_data_from_numpy(np.zeros(1, dtype=np.uint32)),
+        ], request_id="rep", enable_empty_final_response=final, outputs=outputs)
+
+    def summarise(pairs):
+        rows = []
+        for result, error in pairs:
+            assert error is None, error
+            resp = result.get_response()
+            flag = resp.parameters["triton_final_response"].bool_param if "triton_final_response" in resp.parameters \
+                else None
+            rows.append((resp.id, resp.model_name, resp.model_version, [o.name for o in resp.outputs], flag,
+                         None if not resp.outputs else int(result.as_numpy(resp.outputs[0].name)[0]),
+                         None if len(resp.outputs) < 2 else int(result.as_numpy("IDX")[0])))
+        return rows
+
+    expected = len(values) + (1 if final else 0)
+    before = _handled(on)
+    a = summarise(_stream_collect(on.grpc_url, send, expected))
+    b = summarise(_stream_collect(off.grpc_url, send, expected))
+    assert a == b and _handled(on) == before + 1
+    assert [r[5] for r in a[:len(values)]] == [int(v) for v in values]
+    assert [r[6] for r in a[:len(values)]] == list(range(len(values)))
+    if final:
+        assert a[-1][3] == [] and a[-1][4] is True and all(r[4] is False for r in a[:-1])
+    # a subset of the outputs
+    only_idx = [grpcclient.InferRequestedOutput("IDX")]
+    a = summarise(_stream_collect(on.grpc_url, lambda c: send(c, outputs=only_idx), expected))
+    b = summarise(_stream_collect(off.grpc_url, lambda c: send(c, outputs=only_idx), expected))
+    assert a == b and a[0][3] == ["IDX"]
+    # responses that have to wait are produced by the general path
+    before = _handled(on)
+    delays = np.array([0, 2, 0, 1, 0], dtype=np.uint32)
+    a = summarise(_stream_collect(on.grpc_url, lambda c: send(c, delays=delays), expected))
+    assert _handled(on) == before and [r[5] for r in a[:len(values)]] == [int(v) for v in values]
+    # the unary call keeps refusing a decoupled model
+    with grpcclient.InferenceServerClient(on.grpc_url) as c:
+        with pytest.raises(InferenceServerException, match="decoupled"):
+            c.infer("repeat_int32", [
+                grpcclient.InferInput("IN", [5], "INT32").set_data_from_numpy(values),
+                grpcclient.InferInput("DELAY", [5], "UINT32").set_data_from_numpy(np.zeros(5, dtype=np.uint32)),
+                grpcclient.InferInput("WAIT", [1], "UINT32").set_data_from_numpy(np.zeros(1, dtype=np.uint32))])
+
+
+def test_ordinary_models_over_streams(servers):
+    """`simple` through async_stream_infer: native answers keep the order of the requests; the statistics count them."""
+    on, off = servers
+    a = np.arange(16, dtype=np.int32).reshape(1, 16)
+
+    def send(c):
+        for k in range(12):
+            c.async_stream_infer("simple", _inputs(grpcclient, a + k, a), request_id=str(k),
+                                 enable_empty_final_response=(k % 2 == 0))
+
+    before = _handled(on)
+    with grpcclient.InferenceServerClient(on.grpc_url) as c:
+        s0 = c.get_inference_statistics("simple").model_stats[0].inference_count
+    rows = []
+    for srv in (on, off):
+        pairs = _stream_collect(srv.grpc_url, send, 12)
+        assert all(e is None for _, e in pairs)
+        rows.append(sorted((int(r.get_response().id), r.as_numpy("OUTPUT0").tolist(),
+                            r.get_response().parameters["triton_final_response"].bool_param
+                            if "triton_final_response" in r.get_response().parameters else None) for r, _ in pairs))
+        if srv is on:
+            assert [int(r.get_response().id) for r, _ in pairs] == list(range(12))
+    assert rows[0] == rows[1] and _handled(on) == before + 12
+    assert rows[0][0][2] is True and rows[0][1][2] is None
+    with grpcclient.InferenceServerClient(on.grpc_url) as c:
+        assert c.get_inference_statistics("simple").model_stats[0].inference_count - s0 == 12

@@ -355,6 +355,7 @@ class RepeatInt32(Model):
 
     name = "repeat_int32"
     decoupled = True
+    native_kernel = "repeat"  # stream requests without delays are answered in C++ (tca/native_executor.h)
     inputs = [TensorSpec("IN", "INT32", [-1]), TensorSpec("DELAY", "UINT32", [-1]), TensorSpec("WAIT", "UINT32", [1])]
     outputs = [TensorSpec("OUT", "INT32", [1]), TensorSpec("IDX", "UINT32", [1])]
 

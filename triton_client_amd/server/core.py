@@ -650,8 +650,8 @@ class InferenceCore:
             return
         model = lm.model
         kernel = getattr(model, "native_kernel", None)
-        eligible = present and kernel and model.device == "cpu" and not model.parameters and not model.decoupled \
-            and not getattr(model, "sequence", False)
+        eligible = present and kernel and model.device == "cpu" and not model.parameters \
+            and not getattr(model, "sequence", False) and (not model.decoupled or kernel == "repeat")
         if not eligible:
             executor.remove_model(model.name)
             return

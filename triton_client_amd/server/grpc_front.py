@@ -116,6 +116,13 @@ def request_from_proto(msg, streaming=False, raw=None):
     return req
 
 
+def mark_final(req, response):
+    """A one-response model on a stream: its response is the final one, and says so when the
+    request asked for the final-response marker (``triton_enable_empty_final_response``)."""
+    if req.parameters.get("triton_enable_empty_final_response"):
+        response.parameters["triton_final_response"] = True
+
+
 def _set_param(p, value):
     if isinstance(value, bool):
         p.bool_param = value
@@ -332,8 +339,10 @@ class Servicer(service_pb2_grpc.GRPCInferenceServiceServicer):
         def run(msg):
             try:
                 try:
-                    result = self.core.infer(request_from_proto(msg, streaming=True))
+                    req = request_from_proto(msg, streaming=True)
+                    result = self.core.infer(req)
                     if hasattr(result, "outputs"):
+                        mark_final(req, result)
                         out.put(pb.ModelStreamInferResponse(infer_response=response_to_proto(result)))
                     else:
                         for item in result:

@@ -23,7 +23,7 @@ from concurrent import futures
 
 from ..grpc import service_pb2 as pb
 from .core import ASYNC, ServerError
-from .grpc_front import Servicer, request_from_proto, response_to_proto
+from .grpc_front import Servicer, mark_final, request_from_proto, response_to_proto
 
 # gRPC status codes
 _OK, _INVALID_ARGUMENT, _NOT_FOUND, _UNIMPLEMENTED, _INTERNAL, _UNAVAILABLE = 0, 3, 5, 12, 13, 14
@@ -260,6 +260,7 @@ class NativeGrpcFront:
             if err is not None:
                 self._stream_error(call, st, msg, str(getattr(err, "message", err)))
                 return
+            mark_final(req, resp)
             self._stream_send(call, st, req.model_name, pb.ModelStreamInferResponse(
                 infer_response=response_to_proto(resp)))
             self._stream_done(call, st)
