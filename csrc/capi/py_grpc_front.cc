@@ -253,11 +253,22 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   self->funnel = threads > 1 ? new tca::capi::GilFunnel() : nullptr;
   h.on_unary = [self](uint64_t call, const std::string& method, std::string&& request) {
     if (self->native != nullptr && method == "ModelInfer") {
+      using Outcome = tca::server::NativeExecutor::Outcome;
       std::string response;
-      if ((*self->native)->TryGrpc(request, &response)) {  // answered on this reactor thread, no interpreter
+      const Outcome outcome = (*self->native)->TryGrpcAsync(&request, &response, [self, call](bool ok, std::string&& payload) {
+        if (ok) {  // answered by the executor's batch thread
+          self->front->Reply(call, std::move(payload));
+          return;
+        }
+        // the device refused it: the general path takes the request and words the error
+        auto req = std::make_shared<std::string>(std::move(payload));
+        WithGil(self, [self, call, req] { DeliverUnary(self, call, "ModelInfer", *req); });
+      });
+      if (outcome == Outcome::kAnswered) {  // on this reactor thread, no interpreter
         self->front->Reply(call, std::move(response));
         return;
       }
+      if (outcome == Outcome::kDeferred) return;
     }
     auto req = std::make_shared<std::string>(std::move(request));
     WithGil(self, [self, call, method, req] { DeliverUnary(self, call, method, *req); });
@@ -292,8 +303,10 @@ void StopFront(PyGrpcFront* self) {
   tca::server::GrpcServerFront* front = self->front;
   tca::capi::GilFunnel* funnel = self->funnel;
   // reactor / funnel threads may be waiting for the GIL inside a callback: let them finish
+  tca::server::NativeExecutor* native = self->native != nullptr ? self->native->get() : nullptr;
   Py_BEGIN_ALLOW_THREADS
   front->Stop();
+  if (native != nullptr) native->Quiesce();  // deferred requests answer through this front (and may need the funnel)
   if (funnel != nullptr) funnel->Stop();
   Py_END_ALLOW_THREADS
 }

@@ -6,6 +6,9 @@
 //   ex.register_region(name, key, offset, byte_size) / ex.unregister_region(name)   # "" = all
 //   ex.take_stats(name) -> None | {"requests", "inferences", "queue_ns", "last_ms", "by_batch": {b: (count, in, infer, out)}}
 //   ex.set_enabled(flag); ex.counters() -> {"handled", "declined"}
+//   ex.enable_device_bytes(submit_address, wait_address, pipe, stream, device, max_requests, max_count, max_stream_bytes)
+//   ex.disable_device_bytes(); ex.quiesce()
+//   ex.register_device_region(name, address, byte_size, device) / ex.unregister_device_region(name, timeout_ms) -> bool
 //
 // The serving fronts take the object as their `native=` argument and offer it every inference
 // request before Python sees it (tca/native_executor.h).
@@ -169,6 +172,75 @@ PyObject* Counters(PyObject* self_obj, PyObject*) {
                        static_cast<unsigned long long>((*self->ex)->Declined()));
 }
 
+PyObject* EnableDeviceBytes(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  unsigned long long submit = 0, wait = 0, pipe = 0, stream = 0, max_stream = 0;
+  int device = 0, max_requests = 0, max_count = 0;
+  if (!PyArg_ParseTuple(args, "KKKKiiiK", &submit, &wait, &pipe, &stream, &device, &max_requests, &max_count, &max_stream))
+    return nullptr;
+  tca::server::NativeExecutor::DevicePipe p;
+  p.submit = reinterpret_cast<decltype(p.submit)>(static_cast<uintptr_t>(submit));
+  p.wait = reinterpret_cast<decltype(p.wait)>(static_cast<uintptr_t>(wait));
+  p.pipe = reinterpret_cast<void*>(static_cast<uintptr_t>(pipe));
+  p.stream = reinterpret_cast<void*>(static_cast<uintptr_t>(stream));
+  p.device = device;
+  p.max_requests = max_requests;
+  p.max_count = max_count;
+  p.max_stream_bytes = max_stream;
+  tca::Error e;
+  Py_BEGIN_ALLOW_THREADS
+  e = (*self->ex)->EnableDeviceBytes(p);
+  Py_END_ALLOW_THREADS
+  if (!e.IsOk()) {
+    PyErr_SetString(PyExc_ValueError, e.Message().c_str());
+    return nullptr;
+  }
+  Py_RETURN_NONE;
+}
+
+PyObject* DisableDeviceBytes(PyObject* self_obj, PyObject*) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  Py_BEGIN_ALLOW_THREADS  // answers in flight may need the interpreter lock to be delivered
+  (*self->ex)->DisableDeviceBytes();
+  Py_END_ALLOW_THREADS
+  Py_RETURN_NONE;
+}
+
+PyObject* Quiesce(PyObject* self_obj, PyObject*) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  Py_BEGIN_ALLOW_THREADS
+  (*self->ex)->Quiesce();
+  Py_END_ALLOW_THREADS
+  Py_RETURN_NONE;
+}
+
+PyObject* RegisterDeviceRegion(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = nullptr;
+  unsigned long long address = 0, size = 0;
+  int device = 0;
+  if (!PyArg_ParseTuple(args, "sKKi", &name, &address, &size, &device)) return nullptr;
+  const tca::Error e = (*self->ex)->RegisterDeviceRegion(name, address, size, device);
+  if (!e.IsOk()) {
+    PyErr_SetString(PyExc_ValueError, e.Message().c_str());
+    return nullptr;
+  }
+  Py_RETURN_NONE;
+}
+
+PyObject* UnregisterDeviceRegion(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = "";
+  int timeout_ms = 10000;
+  if (!PyArg_ParseTuple(args, "|si", &name, &timeout_ms)) return nullptr;
+  const std::string region(name);
+  bool idle = false;
+  Py_BEGIN_ALLOW_THREADS
+  idle = (*self->ex)->UnregisterDeviceRegion(region, timeout_ms);
+  Py_END_ALLOW_THREADS
+  return PyBool_FromLong(idle ? 1 : 0);
+}
+
 PyMethodDef kMethods[] = {
     {"set_model", SetModel, METH_VARARGS, "set_model(name, version, max_batch, inputs, outputs, kernel)"},
     {"remove_model", RemoveModel, METH_VARARGS, "remove_model(name)"},
@@ -177,6 +249,13 @@ PyMethodDef kMethods[] = {
     {"take_stats", TakeStats, METH_VARARGS, "take_stats(name): statistics accumulated since the last call, or None"},
     {"set_enabled", SetEnabled, METH_VARARGS, "set_enabled(flag)"},
     {"counters", Counters, METH_NOARGS, "requests handled natively / looked at and handed on"},
+    {"enable_device_bytes", EnableDeviceBytes, METH_VARARGS,
+     "enable_device_bytes(submit_address, wait_address, pipe, stream, device, max_requests, max_count, max_stream_bytes)"},
+    {"disable_device_bytes", DisableDeviceBytes, METH_NOARGS, "answers what is queued and stops the batch thread"},
+    {"quiesce", Quiesce, METH_NOARGS, "blocks until no deferred request is queued or running"},
+    {"register_device_region", RegisterDeviceRegion, METH_VARARGS, "register_device_region(name, address, byte_size, device)"},
+    {"unregister_device_region", UnregisterDeviceRegion, METH_VARARGS,
+     "unregister_device_region([name[, timeout_ms]]) -> False when requests still use the region"},
     {nullptr, nullptr, 0, nullptr}};
 
 }  // namespace

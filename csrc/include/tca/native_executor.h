@@ -15,17 +15,29 @@
 // "identity" (OUTPUT0 = INPUT0) and, over gRPC streams, the decoupled "repeat" (one
 // response per input element, as `src/python/examples/simple_grpc_custom_repeat.py` uses).
 //
+// BYTES models whose tensors stay in device shared memory ("bytes_add_sub" on `simple_string`,
+// "bytes_identity" on `simple_identity`; the reference drives them through
+// `src/python/examples/simple_grpc_cudashm_string_client.py`-style callers): the request is
+// decoded on the reactor thread and queued; one batch thread hands whole groups of requests
+// to the device pipeline (prefix walk, decimal arithmetic, packing into the callers' regions:
+// three kernel launches per group) and answers them from there (TryGrpcAsync).  The pipeline
+// itself lives in the HIP library; this file only sees its C entry points (DevicePipe).
+//
 // Statistics are accumulated here and collected by the Python core (TakeStats), so the
 // model statistics endpoints keep counting requests that never reached Python.
 #pragma once
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -44,8 +56,24 @@ class NativeExecutor {
     std::string name, version;  // version = the one unversioned requests resolve to
     int max_batch = 0;
     std::vector<TensorSpec> inputs, outputs;
-    std::string kernel;  // "add_sub" | "identity"
+    std::string kernel;  // "add_sub" | "identity" | "repeat" | "bytes_add_sub" | "bytes_identity"
   };
+  // C entry points of the device BYTES pipeline (`csrc/hip/bytes_models.hip`) plus one pipeline
+  // object and the stream its batches run on; all owned by the caller, alive until
+  // DisableDeviceBytes has returned.
+  struct DevicePipe {
+    int (*submit)(void* pipe, int op, int n, int count, const uint64_t* in_ptrs, const uint64_t* in_bytes,
+                  const uint64_t* out_ptrs, const uint64_t* out_caps, void* stream) = nullptr;
+    int (*wait)(void* pipe, int n, uint32_t* codes, uint64_t* out_bytes) = nullptr;
+    void* pipe = nullptr;
+    void* stream = nullptr;
+    int device = 0, max_requests = 0, max_count = 0;
+    uint64_t max_stream_bytes = 0;
+  };
+  enum class Outcome { kDeclined, kAnswered, kDeferred };
+  // ok: `payload` is the serialized response.  Not ok: the device refused the request (malformed stream,
+  // output range too small...): `payload` is the request, which the caller hands to the general path.
+  using Completion = std::function<void(bool ok, std::string&& payload)>;
   struct BatchStats {
     uint64_t count = 0, input_ns = 0, infer_ns = 0, output_ns = 0;
   };
@@ -62,8 +90,28 @@ class NativeExecutor {
   void UnregisterRegion(const std::string& name);  // "" = all
   void SetEnabled(bool on) { enabled_.store(on); }
 
+  NativeExecutor();
+  ~NativeExecutor();
+  NativeExecutor(const NativeExecutor&) = delete;
+  NativeExecutor& operator=(const NativeExecutor&) = delete;
+
+  // Starts (or, with other arguments, restarts) the batch thread of the device BYTES path.
+  Error EnableDeviceBytes(const DevicePipe& pipe);
+  // Answers what is queued, then stops the batch thread.
+  void DisableDeviceBytes();
+  // A registered device shared-memory region: `size` bytes at device address `address` on GPU `device`.
+  Error RegisterDeviceRegion(const std::string& name, uint64_t address, uint64_t size, int device);
+  // Stops new requests on the region ("" = all), then waits for the queued ones that name it.  False: still
+  // in use after `timeout_ms` (the region stays registered).
+  bool UnregisterDeviceRegion(const std::string& name, int timeout_ms);
+  // Blocks until no deferred request is queued or running.
+  void Quiesce();
+
   // `request` = serialized ModelInferRequest; true: `response` holds the serialized ModelInferResponse.
   bool TryGrpc(const std::string& request, std::string* response);
+  // TryGrpc plus the device BYTES path.  kDeferred: `*request` has been moved into the queue and `done`
+  // runs later on the batch thread.
+  Outcome TryGrpcAsync(std::string* request, std::string* response, Completion done);
   // One message of a ModelStreamInfer call; true: `responses` holds the serialized ModelStreamInferResponse
   // messages to send, in order (one for the ordinary kernels, one per element - plus the empty final one
   // when the request asks for it - for the decoupled "repeat" kernel).
@@ -92,8 +140,17 @@ class NativeExecutor {
     std::mutex stats_mu;
     Stats stats;
   };
+  struct DeviceRegion {
+    uint64_t address = 0, size = 0;
+    int device = 0;
+    std::atomic<int> inflight{0};
+  };
   struct Request;
   struct Result;
+  struct DeviceJob;
+  bool PrepareDeviceJob(Request* req, const std::shared_ptr<Model>& model, DeviceJob* job);
+  void DeviceLoop();
+  void FinishDeviceJob(DeviceJob* job, bool ok);
   static void BuildGrpcResponse(const Request& req, const std::vector<Result>& results, int final_flag,
                                 std::string* response);
   bool Run(Request* req, const std::shared_ptr<Model>& model);
@@ -106,6 +163,17 @@ class NativeExecutor {
   std::shared_mutex mu_;
   std::map<std::string, std::shared_ptr<Model>> models_;
   std::map<std::string, std::shared_ptr<Region>> regions_;
+  std::map<std::string, std::shared_ptr<DeviceRegion>> device_regions_;
+
+  // device BYTES path
+  DevicePipe pipe_;
+  std::atomic<bool> pipe_on_{false};
+  std::thread batch_thread_;
+  std::mutex q_mu_;
+  std::condition_variable q_cv_, idle_cv_;
+  std::deque<std::unique_ptr<DeviceJob>> queue_;
+  size_t running_ = 0;  // taken off the queue, not yet answered
+  bool stop_ = false;
 };
 
 }  // namespace server

@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <thread>
 
 #include "tca/json.h"
 #include "tca/pbwire.h"
@@ -16,7 +17,7 @@ namespace tca {
 namespace server {
 namespace {
 
-enum Kernel { kAddSub = 1, kIdentity = 2, kRepeat = 3 };
+enum Kernel { kAddSub = 1, kIdentity = 2, kRepeat = 3, kBytesAddSub = 4, kBytesIdentity = 5 };
 
 size_t ItemSize(const std::string& dt) {
   if (dt == "INT8" || dt == "UINT8" || dt == "BOOL") return 1;
@@ -100,9 +101,28 @@ struct NativeExecutor::Request {
   uint64_t t_arrive = 0;
 };
 
+// One request on its way through the device BYTES pipeline.
+struct NativeExecutor::DeviceJob {
+  Request req;  // results already describe the answer; the kernels fill the regions
+  std::shared_ptr<Model> model;
+  std::string request_bytes;  // handed back when the device refuses the request
+  Completion done;
+  int op = 0;
+  uint32_t count = 0;
+  int batch = 1;
+  int n_in = 0, n_out = 0;
+  uint64_t in_ptrs[2] = {0, 0}, in_bytes[2] = {0, 0}, out_ptrs[2] = {0, 0}, out_caps[2] = {0, 0};
+  std::vector<std::shared_ptr<DeviceRegion>> leases;
+  uint64_t t0 = 0, t1 = 0;
+};
+
 NativeExecutor::Region::~Region() {
   if (map != nullptr) munmap(map, map_size);
 }
+
+NativeExecutor::NativeExecutor() = default;
+
+NativeExecutor::~NativeExecutor() { DisableDeviceBytes(); }
 
 Error NativeExecutor::SetModel(const ModelSpec& spec) {
   auto m = std::make_shared<Model>();
@@ -113,6 +133,17 @@ Error NativeExecutor::SetModel(const ModelSpec& spec) {
   } else if (spec.kernel == "identity") {
     if (spec.inputs.size() != 1 || spec.outputs.size() != 1) return Error("identity needs one input and one output");
     m->kernel = kIdentity;
+  } else if (spec.kernel == "bytes_add_sub" || spec.kernel == "bytes_identity") {
+    const size_t arity = spec.kernel == "bytes_add_sub" ? 2 : 1;
+    if (spec.inputs.size() != arity || spec.outputs.size() != arity) return Error(spec.kernel + ": wrong number of tensors");
+    for (const auto& t : spec.inputs)
+      if (t.datatype != "BYTES") return Error(spec.kernel + " takes BYTES tensors");
+    for (const auto& t : spec.outputs)
+      if (t.datatype != "BYTES") return Error(spec.kernel + " produces BYTES tensors");
+    m->kernel = arity == 2 ? kBytesAddSub : kBytesIdentity;
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    models_[spec.name] = std::move(m);
+    return Error::Success();
   } else if (spec.kernel == "repeat") {
     // decoupled: IN INT32[-1], DELAY UINT32[-1], WAIT UINT32[1] -> one response (OUT INT32[1], IDX UINT32[1]) per element
     if (spec.max_batch != 0 || spec.inputs.size() != 3 || spec.outputs.size() != 2) return Error("repeat needs IN, DELAY, WAIT and OUT, IDX");
@@ -197,6 +228,7 @@ bool NativeExecutor::TakeStats(const std::string& name, Stats* out) {
 bool NativeExecutor::Run(Request* req, const std::shared_ptr<Model>& model) {
   const ModelSpec& spec = model->spec;
   const uint64_t t0 = NowNs();
+  if (model->kernel != kAddSub && model->kernel != kIdentity) return false;
   if (req->inputs.size() != spec.inputs.size()) return false;
   const Request::Input* ordered[2] = {nullptr, nullptr};
   int64_t batch = 0;
@@ -686,6 +718,294 @@ bool NativeExecutor::TryGrpcStream(const std::string& request, std::vector<std::
   responses->push_back(std::move(wrapped));
   handled_.fetch_add(1, std::memory_order_relaxed);
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BYTES tensors in device shared memory
+// ---------------------------------------------------------------------------------------------
+Error NativeExecutor::EnableDeviceBytes(const DevicePipe& pipe) {
+  if (pipe.submit == nullptr || pipe.wait == nullptr || pipe.pipe == nullptr || pipe.max_requests <= 0 ||
+      pipe.max_count <= 0 || pipe.max_stream_bytes == 0)
+    return Error("device BYTES path: incomplete pipeline description");
+  DisableDeviceBytes();
+  pipe_ = pipe;
+  {
+    std::lock_guard<std::mutex> lk(q_mu_);
+    stop_ = false;
+  }
+  batch_thread_ = std::thread([this] { DeviceLoop(); });
+  pipe_on_.store(true);
+  return Error::Success();
+}
+
+void NativeExecutor::DisableDeviceBytes() {
+  pipe_on_.store(false);  // no new jobs; a request that saw `true` a moment ago is still answered below
+  {
+    std::lock_guard<std::mutex> lk(q_mu_);
+    stop_ = true;
+  }
+  q_cv_.notify_all();
+  if (batch_thread_.joinable()) batch_thread_.join();
+}
+
+Error NativeExecutor::RegisterDeviceRegion(const std::string& name, uint64_t address, uint64_t size, int device) {
+  if (address == 0 || address + size < address) return Error("device region '" + name + "': invalid address range");
+  auto r = std::make_shared<DeviceRegion>();
+  r->address = address;
+  r->size = size;
+  r->device = device;
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  device_regions_[name] = std::move(r);
+  return Error::Success();
+}
+
+bool NativeExecutor::UnregisterDeviceRegion(const std::string& name, int timeout_ms) {
+  std::vector<std::pair<std::string, std::shared_ptr<DeviceRegion>>> going;
+  {
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    if (name.empty()) {
+      for (auto& kv : device_regions_) going.emplace_back(kv.first, kv.second);
+      device_regions_.clear();
+    } else {
+      auto it = device_regions_.find(name);
+      if (it != device_regions_.end()) {
+        going.emplace_back(it->first, it->second);
+        device_regions_.erase(it);
+      }
+    }
+  }
+  // leases are only taken under mu_ from the map: nothing new can start on these regions
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
+  bool idle = true;
+  for (auto& kv : going) {
+    while (kv.second->inflight.load(std::memory_order_acquire) > 0) {
+      if (std::chrono::steady_clock::now() >= deadline) {
+        idle = false;
+        break;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+  if (!idle) {
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    for (auto& kv : going) device_regions_.emplace(kv.first, kv.second);  // still serving requests: stays registered
+  }
+  return idle;
+}
+
+void NativeExecutor::Quiesce() {
+  std::unique_lock<std::mutex> lk(q_mu_);
+  idle_cv_.wait(lk, [this] { return queue_.empty() && running_ == 0; });
+}
+
+// Validates a request for a BYTES model as far as the general path would before it queues the request
+// for the device, and describes the job.  False = not ours.
+bool NativeExecutor::PrepareDeviceJob(Request* req, const std::shared_ptr<Model>& model, DeviceJob* job) {
+  const ModelSpec& spec = model->spec;
+  job->t0 = NowNs();
+  const size_t arity = spec.inputs.size();
+  if (req->inputs.size() != arity || req->outputs.size() != arity) return false;  // outputs must name their regions
+  const Request::Input* ordered[2] = {nullptr, nullptr};
+  const size_t lead = spec.max_batch > 0 ? 1 : 0;
+  uint64_t count = 0;
+  for (const auto& in : req->inputs) {
+    size_t slot = arity;
+    for (size_t k = 0; k < arity; ++k)
+      if (spec.inputs[k].name == in.name) slot = k;
+    if (slot == arity || ordered[slot] != nullptr) return false;
+    const TensorSpec& ts = spec.inputs[slot];
+    if (in.datatype != "BYTES" || !in.shm.set || in.has_data) return false;
+    if (in.shape.size() != ts.dims.size() + lead) return false;
+    uint64_t n = 1;
+    for (size_t d = 0; d < in.shape.size(); ++d) {
+      const int64_t v = in.shape[d];
+      if (v < 1 || v > pipe_.max_count) return false;
+      if (d >= lead && ts.dims[d - lead] != -1 && ts.dims[d - lead] != v) return false;
+      n *= static_cast<uint64_t>(v);
+      if (n > static_cast<uint64_t>(pipe_.max_count)) return false;
+    }
+    if (lead && in.shape[0] > spec.max_batch) return false;
+    if (count != 0 && (n != count || in.shape != req->inputs[0].shape)) return false;
+    count = n;
+    ordered[slot] = &in;
+  }
+  job->count = static_cast<uint32_t>(count);
+  job->batch = lead ? static_cast<int>(ordered[0]->shape[0]) : 1;
+  job->op = model->kernel == kBytesAddSub ? 0 : 1;
+  job->n_in = job->n_out = static_cast<int>(arity);
+  const Request::Output* wanted[2] = {nullptr, nullptr};
+  for (const auto& o : req->outputs) {
+    size_t slot = arity;
+    for (size_t k = 0; k < arity; ++k)
+      if (spec.outputs[k].name == o.name) slot = k;
+    if (slot == arity || wanted[slot] != nullptr || !o.shm.set) return false;
+    wanted[slot] = &o;
+  }
+  {
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    auto lease = [&](const ShmRef& ref, bool input, uint64_t* address) {
+      auto it = device_regions_.find(ref.region);
+      if (it == device_regions_.end() || it->second->device != pipe_.device) return false;
+      const DeviceRegion& r = *it->second;
+      if (ref.offset < 0 || ref.size < (input ? 1 : 0)) return false;
+      const uint64_t off = static_cast<uint64_t>(ref.offset), size = static_cast<uint64_t>(ref.size);
+      if (off + size < off || off + size > r.size) return false;
+      if (input && size > pipe_.max_stream_bytes) return false;
+      *address = r.address + off;
+      it->second->inflight.fetch_add(1, std::memory_order_acq_rel);
+      job->leases.push_back(it->second);
+      return true;
+    };
+    bool ok = true;
+    for (size_t k = 0; ok && k < arity; ++k) {
+      ok = lease(ordered[k]->shm, true, &job->in_ptrs[k]);
+      job->in_bytes[k] = static_cast<uint64_t>(ordered[k]->shm.size);
+    }
+    for (size_t k = 0; ok && k < arity; ++k) {
+      ok = lease(wanted[k]->shm, false, &job->out_ptrs[k]);
+      job->out_caps[k] = static_cast<uint64_t>(wanted[k]->shm.size);
+    }
+    if (!ok) {
+      for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
+      job->leases.clear();
+      return false;
+    }
+  }
+  req->results.clear();
+  for (const auto& o : req->outputs) {  // in the order the request names them
+    Result r;
+    r.name = o.name;
+    r.datatype = "BYTES";
+    r.shape = ordered[0]->shape;
+    r.shm = o.shm;
+    req->results.push_back(std::move(r));
+  }
+  req->version_used = spec.version;
+  job->t1 = NowNs();
+  return true;
+}
+
+void NativeExecutor::FinishDeviceJob(DeviceJob* job, bool ok) {
+  std::string payload;
+  if (ok) {
+    BuildGrpcResponse(job->req, job->req.results, -1, &payload);
+    const uint64_t now = NowNs();
+    std::lock_guard<std::mutex> lk(job->model->stats_mu);
+    Stats& s = job->model->stats;
+    ++s.requests;
+    s.inferences += static_cast<uint64_t>(job->batch);
+    s.queue_ns += job->t0 - job->req.t_arrive;
+    s.last_ms = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::milliseconds>(
+                                          std::chrono::system_clock::now().time_since_epoch()).count());
+    BatchStats& bs = s.by_batch[job->batch];
+    ++bs.count;
+    bs.input_ns += job->t1 - job->t0;
+    bs.infer_ns += now - job->t1;
+    handled_.fetch_add(1, std::memory_order_relaxed);
+  } else {
+    payload = std::move(job->request_bytes);
+    declined_.fetch_add(1, std::memory_order_relaxed);
+  }
+  // the regions are free again before the caller hears about it: it may unregister them right away
+  for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
+  job->leases.clear();
+  job->done(ok, std::move(payload));
+}
+
+void NativeExecutor::DeviceLoop() {
+  const size_t limit = static_cast<size_t>(pipe_.max_requests);
+  std::vector<std::unique_ptr<DeviceJob>> batch;
+  std::vector<uint64_t> in_ptrs, in_bytes, out_ptrs, out_caps, produced(2 * limit);
+  std::vector<uint32_t> codes(limit);
+  for (;;) {
+    batch.clear();
+    {
+      std::unique_lock<std::mutex> lk(q_mu_);
+      q_cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
+      if (queue_.empty()) return;  // stopping, and everything has been answered
+      // one launch group = requests of one operation and element count, oldest first
+      const int op = queue_.front()->op;
+      const uint32_t count = queue_.front()->count;
+      for (auto it = queue_.begin(); it != queue_.end() && batch.size() < limit;) {
+        if ((*it)->op == op && (*it)->count == count) {
+          batch.push_back(std::move(*it));
+          it = queue_.erase(it);
+        } else {
+          ++it;
+        }
+      }
+      running_ += batch.size();
+    }
+    in_ptrs.clear();
+    in_bytes.clear();
+    out_ptrs.clear();
+    out_caps.clear();
+    for (const auto& job : batch) {
+      for (int k = 0; k < job->n_in; ++k) {
+        in_ptrs.push_back(job->in_ptrs[k]);
+        in_bytes.push_back(job->in_bytes[k]);
+      }
+      for (int k = 0; k < job->n_out; ++k) {
+        out_ptrs.push_back(job->out_ptrs[k]);
+        out_caps.push_back(job->out_caps[k]);
+      }
+    }
+    const int n = static_cast<int>(batch.size());
+    int rc = pipe_.submit(pipe_.pipe, batch[0]->op, n, static_cast<int>(batch[0]->count), in_ptrs.data(), in_bytes.data(),
+                          out_ptrs.data(), out_caps.data(), pipe_.stream);
+    if (rc == 0) rc = pipe_.wait(pipe_.pipe, n, codes.data(), produced.data());
+    for (int i = 0; i < n; ++i) FinishDeviceJob(batch[static_cast<size_t>(i)].get(), rc == 0 && codes[static_cast<size_t>(i)] == 0);
+    {
+      std::lock_guard<std::mutex> lk(q_mu_);
+      running_ -= batch.size();
+      if (queue_.empty() && running_ == 0) idle_cv_.notify_all();
+    }
+  }
+}
+
+NativeExecutor::Outcome NativeExecutor::TryGrpcAsync(std::string* request, std::string* response, Completion done) {
+  if (!enabled_.load(std::memory_order_relaxed)) return Outcome::kDeclined;
+  auto job = std::make_unique<DeviceJob>();
+  std::shared_ptr<Model> model;
+  if (!ParseGrpc(*request, false, &job->req, &model)) return Outcome::kDeclined;
+  if (model->kernel == kRepeat) return Outcome::kDeclined;
+  if (model->kernel == kBytesAddSub || model->kernel == kBytesIdentity) {
+    if (!pipe_on_.load(std::memory_order_acquire) || !PrepareDeviceJob(&job->req, model, job.get())) {
+      declined_.fetch_add(1, std::memory_order_relaxed);
+      return Outcome::kDeclined;
+    }
+    job->req.inputs.clear();  // pointed into the request bytes, which move now
+    job->model = std::move(model);
+    job->request_bytes = std::move(*request);
+    job->done = std::move(done);
+    {
+      std::lock_guard<std::mutex> lk(q_mu_);
+      if (stop_) {  // the batch thread is going away: hand the request back untouched
+        *request = std::move(job->request_bytes);
+        for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
+        return Outcome::kDeclined;
+      }
+      queue_.push_back(std::move(job));
+    }
+    q_cv_.notify_one();
+    return Outcome::kDeferred;
+  }
+  Request& req = job->req;
+  if (!Run(&req, model)) {
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return Outcome::kDeclined;
+  }
+  const uint64_t t2 = NowNs();
+  BuildGrpcResponse(req, req.results, -1, response);
+  {
+    int batch = 1;
+    if (model->spec.max_batch > 0 && !req.results.empty() && !req.results[0].shape.empty())
+      batch = static_cast<int>(req.results[0].shape[0]);
+    std::lock_guard<std::mutex> lk(model->stats_mu);
+    model->stats.by_batch[batch].output_ns += NowNs() - t2;
+  }
+  handled_.fetch_add(1, std::memory_order_relaxed);
+  return Outcome::kAnswered;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -3,12 +3,17 @@
 // memory) through one NativeExecutor while other threads keep replacing the model, registering
 // and unregistering the regions and collecting statistics.  Every answered request is checked;
 // a declined one is fine (the model or a region was just away), a wrong one is not.
+// A second part drives the device BYTES path (deferred answers from the executor's batch thread)
+// against a host stand-in for the HIP pipeline while the region is unregistered and re-registered.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
 #include <cstring>
 #include <iostream>
 #include <thread>
@@ -114,6 +119,262 @@ bool CheckSumDiff(const void* sum, const void* diff, const int32_t* a, const int
     if (s != a[i] + b[i] || d != a[i] - b[i]) return false;
   }
   return true;
+}
+
+// ---- device BYTES path, with a stand-in for the HIP pipeline that works on host memory ----------------
+// The executor only sees the pipeline's C entry points; these two do on the host what the kernels do on the
+// device (walk the length-prefixed streams, add / subtract the decimals, pack the results), so "device
+// addresses" are plain pointers here.
+struct FakePipe {
+  int n = 0, op = 0, count = 0;
+  std::vector<uint32_t> codes;
+  std::vector<uint64_t> produced;
+  std::atomic<int> batches{0}, largest{0};
+};
+
+bool WalkStream(const uint8_t* p, uint64_t size, int count, std::vector<std::string>* out) {
+  uint64_t at = 0;
+  for (int e = 0; e < count; ++e) {
+    if (at + 4 > size) return false;
+    uint32_t len;
+    std::memcpy(&len, p + at, 4);
+    at += 4;
+    if (at + len > size) return false;
+    out->emplace_back(reinterpret_cast<const char*>(p + at), len);
+    at += len;
+  }
+  return at == size;
+}
+
+bool PackStream(const std::vector<std::string>& items, uint8_t* dst, uint64_t cap, uint64_t* total) {
+  uint64_t at = 0;
+  for (const auto& s : items) {
+    if (at + 4 + s.size() > cap) return false;
+    const uint32_t len = static_cast<uint32_t>(s.size());
+    std::memcpy(dst + at, &len, 4);
+    std::memcpy(dst + at + 4, s.data(), s.size());
+    at += 4 + s.size();
+  }
+  *total = at;
+  return true;
+}
+
+int FakeSubmit(void* pipe, int op, int n, int count, const uint64_t* in_ptrs, const uint64_t* in_bytes,
+               const uint64_t* out_ptrs, const uint64_t* out_caps, void*) {
+  auto* p = static_cast<FakePipe*>(pipe);
+  p->n = n;
+  p->codes.assign(static_cast<size_t>(n), 0);
+  p->produced.assign(2 * static_cast<size_t>(n), 0);
+  ++p->batches;
+  if (n > p->largest.load()) p->largest.store(n);
+  const int arity = op == 0 ? 2 : 1;
+  for (int i = 0; i < n; ++i) {
+    std::vector<std::string> in[2];
+    bool ok = true;
+    for (int k = 0; k < arity; ++k)
+      ok = ok && WalkStream(reinterpret_cast<const uint8_t*>(in_ptrs[i * arity + k]), in_bytes[i * arity + k], count, &in[k]);
+    if (!ok) {
+      p->codes[static_cast<size_t>(i)] = 1;
+      continue;
+    }
+    std::vector<std::string> out[2];
+    if (op == 0) {
+      for (int e = 0; e < count; ++e) {
+        const long long x = std::stoll(in[0][static_cast<size_t>(e)]), y = std::stoll(in[1][static_cast<size_t>(e)]);
+        out[0].push_back(std::to_string(x + y));
+        out[1].push_back(std::to_string(x - y));
+      }
+    } else {
+      out[0] = in[0];
+    }
+    for (int k = 0; k < arity; ++k)
+      if (!PackStream(out[k], reinterpret_cast<uint8_t*>(out_ptrs[i * arity + k]), out_caps[i * arity + k],
+                      &p->produced[2 * static_cast<size_t>(i) + static_cast<size_t>(k)]))
+        p->codes[static_cast<size_t>(i)] = 3;
+  }
+  return 0;
+}
+
+int FakeWait(void* pipe, int n, uint32_t* codes, uint64_t* out_bytes) {
+  auto* p = static_cast<FakePipe*>(pipe);
+  if (n != p->n) return -1;
+  std::this_thread::sleep_for(std::chrono::microseconds(30));  // the length of a real batch
+  for (int i = 0; i < n; ++i) {
+    codes[i] = p->codes[static_cast<size_t>(i)];
+    out_bytes[2 * i] = p->produced[2 * static_cast<size_t>(i)];
+    out_bytes[2 * i + 1] = p->produced[2 * static_cast<size_t>(i) + 1];
+  }
+  return 0;
+}
+
+std::string StringRequest(const std::string& region, int64_t in_size, int64_t slot, int64_t out_cap, bool name_outputs = true) {
+  std::string out;
+  pb::Writer w(&out);
+  w.String(1, "simple_string");
+  w.String(3, "s-1");
+  for (int k = 0; k < 2; ++k) {
+    std::string t, shape;
+    pb::Writer tw(&t), sw(&shape);
+    tw.String(1, k == 0 ? "INPUT0" : "INPUT1");
+    tw.String(2, "BYTES");
+    sw.Varint(1);
+    sw.Varint(16);
+    tw.Message(3, shape);
+    Param(&tw, 4, "shared_memory_region", &region, 0);
+    Param(&tw, 4, "shared_memory_byte_size", nullptr, in_size);
+    Param(&tw, 4, "shared_memory_offset", nullptr, slot + 256 * k);
+    w.Message(5, t);
+  }
+  for (int k = 0; name_outputs && k < 2; ++k) {
+    std::string t;
+    pb::Writer tw(&t);
+    tw.String(1, k == 0 ? "OUTPUT0" : "OUTPUT1");
+    Param(&tw, 2, "shared_memory_region", &region, 0);
+    Param(&tw, 2, "shared_memory_byte_size", nullptr, out_cap);
+    Param(&tw, 2, "shared_memory_offset", nullptr, slot + 512 + 256 * k);
+    w.Message(6, t);
+  }
+  return out;
+}
+
+// Worker threads queue `simple_string` requests whose tensors sit in a registered "device" region while another
+// thread unregisters and re-registers the region; every answer is checked, every refusal must hand the request back.
+void DeviceBytesPath() {
+  NativeExecutor ex;
+  FakePipe fake;
+  NativeExecutor::DevicePipe pipe;
+  pipe.submit = FakeSubmit;
+  pipe.wait = FakeWait;
+  pipe.pipe = &fake;
+  pipe.max_requests = 8;
+  pipe.max_count = 4096;
+  pipe.max_stream_bytes = 1 << 20;
+  NativeExecutor::ModelSpec m;
+  m.name = "simple_string";
+  m.version = "1";
+  m.max_batch = 8;
+  m.kernel = "bytes_add_sub";
+  m.inputs = {{"INPUT0", "BYTES", {16}}, {"INPUT1", "BYTES", {16}}};
+  m.outputs = {{"OUTPUT0", "BYTES", {16}}, {"OUTPUT1", "BYTES", {16}}};
+  if (!ex.SetModel(m).IsOk()) Fail("device bytes: registering the model");
+  std::string probe = StringRequest("dev", 10, 0, 256), response;
+  if (ex.TryGrpcAsync(&probe, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+    Fail("device bytes: accepted without a pipeline");
+  if (!ex.EnableDeviceBytes(pipe).IsOk()) Fail("device bytes: enabling");
+  constexpr int kThreads = 4;
+  constexpr size_t kSlot = 1024;
+  std::vector<uint8_t> memory(kThreads * kSlot);
+  if (!ex.RegisterDeviceRegion("dev", reinterpret_cast<uint64_t>(memory.data()), memory.size(), 0).IsOk())
+    Fail("device bytes: registering the region");
+  {
+    // a stream too short for 16 elements: the device notices, and the request comes back for the general path
+    const std::string copy = probe;
+    std::atomic<int> verdict{-1};
+    std::string returned;
+    if (ex.TryGrpcAsync(&probe, &response, [&](bool ok, std::string&& p) {
+          returned = std::move(p);
+          verdict.store(ok ? 1 : 0);
+        }) != NativeExecutor::Outcome::kDeferred)
+      Fail("device bytes: a well-formed request for registered regions was not queued");
+    ex.Quiesce();
+    if (verdict.load() != 0 || returned != copy) Fail("device bytes: a malformed stream was not handed back");
+  }
+  std::atomic<bool> stop{false};
+  std::atomic<long> answered{0}, refused{0}, declined{0};
+  std::vector<std::thread> workers;
+  for (int t = 0; t < kThreads; ++t) {
+    workers.emplace_back([&, t] {
+      uint8_t* slot = memory.data() + static_cast<size_t>(t) * kSlot;
+      std::mutex mu;
+      std::condition_variable cv;
+      for (int round = 0; !stop.load(); ++round) {
+        std::vector<std::string> a, b;
+        for (int e = 0; e < 16; ++e) {
+          a.push_back(std::to_string(round * 31 + e - 7 * t));
+          b.push_back(std::to_string(e * 3 - round));
+        }
+        uint64_t size_a = 0, size_b = 0;
+        PackStream(a, slot, 256, &size_a);
+        PackStream(b, slot + 256, 256, &size_b);
+        if (size_a != size_b) {  // one byte_size field serves both inputs in this request shape: pad by choosing equal widths
+          continue;
+        }
+        const bool small = round % 7 == 3;  // output range too small: the device refuses, the request comes back
+        std::string request = StringRequest("dev", static_cast<int64_t>(size_a), static_cast<int64_t>(t) * kSlot, small ? 8 : 256);
+        const std::string copy = request;
+        bool done = false, ok = false;
+        std::string payload;
+        const auto outcome = ex.TryGrpcAsync(&request, &response, [&](bool good, std::string&& p) {
+          std::lock_guard<std::mutex> lk(mu);
+          ok = good;
+          payload = std::move(p);
+          done = true;
+          cv.notify_one();
+        });
+        if (outcome == NativeExecutor::Outcome::kDeclined) {
+          if (request != copy) Fail("device bytes: a declined request was consumed");
+          ++declined;
+          continue;
+        }
+        if (outcome != NativeExecutor::Outcome::kDeferred) {
+          Fail("device bytes: answered inline");
+          continue;
+        }
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return done; });
+        }
+        if (!ok) {
+          if (!small || payload != copy) Fail("device bytes: refusal without cause, or without the request");
+          ++refused;
+          continue;
+        }
+        if (small) Fail("device bytes: a result that does not fit was reported as written");
+        std::vector<std::string> sum, diff;
+        uint64_t want_sum = 0, want_diff = 0;
+        std::vector<std::string> es, ed;
+        for (int e = 0; e < 16; ++e) {
+          es.push_back(std::to_string(std::stoll(a[static_cast<size_t>(e)]) + std::stoll(b[static_cast<size_t>(e)])));
+          ed.push_back(std::to_string(std::stoll(a[static_cast<size_t>(e)]) - std::stoll(b[static_cast<size_t>(e)])));
+        }
+        std::vector<uint8_t> expect(512);
+        PackStream(es, expect.data(), 256, &want_sum);
+        PackStream(ed, expect.data() + 256, 256, &want_diff);
+        if (std::memcmp(slot + 512, expect.data(), want_sum) != 0 || std::memcmp(slot + 768, expect.data() + 256, want_diff) != 0)
+          Fail("device bytes: wrong result");
+        if (payload.find("simple_string") == std::string::npos || payload.find("OUTPUT1") == std::string::npos)
+          Fail("device bytes: response without its model or outputs");
+        ++answered;
+      }
+    });
+  }
+  std::thread churn([&] {
+    while (!stop.load()) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(3));
+      if (!ex.UnregisterDeviceRegion("dev", 5000)) Fail("device bytes: the region never became idle");
+      std::this_thread::sleep_for(std::chrono::microseconds(300));
+      if (!ex.RegisterDeviceRegion("dev", reinterpret_cast<uint64_t>(memory.data()), memory.size(), 0).IsOk())
+        Fail("device bytes: registering the region again");
+    }
+  });
+  std::this_thread::sleep_for(std::chrono::milliseconds(1500));
+  stop.store(true);
+  for (auto& w : workers) w.join();
+  churn.join();
+  ex.Quiesce();
+  NativeExecutor::Stats st;
+  if (!ex.TakeStats("simple_string", &st) || st.requests != static_cast<uint64_t>(answered.load()))
+    Fail("device bytes: statistics do not match the answered requests");
+  std::string unnamed = StringRequest("dev", 40, 0, 256, false);
+  if (ex.TryGrpcAsync(&unnamed, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+    Fail("device bytes: outputs without regions must take the general path");
+  ex.DisableDeviceBytes();
+  std::string late = StringRequest("dev", 40, 0, 256);
+  if (ex.TryGrpcAsync(&late, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+    Fail("device bytes: accepted after the pipeline was disabled");
+  std::cout << "device bytes: answered " << answered.load() << ", refused by the device " << refused.load() << ", declined "
+            << declined.load() << ", batches " << fake.batches.load() << " (largest " << fake.largest.load() << ")" << std::endl;
+  if (answered.load() == 0 || refused.load() == 0) Fail("device bytes: nothing was answered or nothing refused");
 }
 
 }  // namespace
@@ -271,6 +532,7 @@ int main() {
   if (ex.TryHttp("simple", "", "{\"inputs\":[]}", 400, &headers, &parts)) Fail("header length past the body accepted");
   munmap(mem, 4096);
   shm_unlink(key);
+  DeviceBytesPath();
   std::cout << "answered " << answered.load() << ", declined " << declined.load() << ", statistics collected for "
             << collected.load() << ", failures " << g_failures.load() << std::endl;
   if (g_failures.load() != 0 || answered.load() == 0) return 1;

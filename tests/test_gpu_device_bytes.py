@@ -11,11 +11,14 @@ import pytest
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
 
 
-@pytest.fixture(scope="module")
-def served():
+@pytest.fixture(scope="module", params=["native", "interpreter"])
+def served(request):
+    """The same server twice: requests queued and answered by the C++ executor's batch thread,
+    and (``TCA_NATIVE_DEVICE_BYTES=0``) by the Python batch thread.  Same kernels, same answers."""
     from triton_client_amd.server import spawn_server
 
-    srv = spawn_server(models=["simple_string", "simple_identity"], gpu=0)
+    env = {"TCA_NATIVE_DEVICE_BYTES": "1" if request.param == "native" else "0"}
+    srv = spawn_server(models=["simple_string", "simple_identity"], gpu=0, env=env)
     yield srv
     srv.stop()
 
@@ -215,3 +218,83 @@ def test_concurrent_requests_share_launches(served):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def _native_handled(http_url):
+    import urllib.request
+
+    with urllib.request.urlopen(f"http://{http_url}/metrics", timeout=10) as r:
+        for line in r.read().decode().splitlines():
+            if line.startswith("tca_native_handled_total "):
+                return int(line.rsplit(" ", 1)[1])
+    raise AssertionError("the server reports no native execution counters")
+
+
+def test_native_executor_answers_and_survives_unregistration():
+    """Requests with all tensors in device regions never reach the interpreter (the executor's
+    counter moves, the model statistics still count them), requests the device refuses come back
+    through the general path with its error text, and a region can be unregistered while other
+    callers keep the executor busy."""
+    import tritonclient.grpc as g
+    import tritonclient.utils.cuda_shared_memory as hipshm
+    from tritonclient.utils import InferenceServerException, serialize_byte_tensor
+
+    from triton_client_amd.server import spawn_server
+
+    vals = np.array([str(7 * i).encode() for i in range(16)], dtype=object).reshape(1, 16)
+    blob = serialize_byte_tensor(vals).item()
+    srv = spawn_server(models=["simple_string"], gpu=0)
+    try:
+        stop = threading.Event()
+        errors = []
+
+        def load(k):
+            try:
+                with g.InferenceServerClient(srv.grpc_url) as c:
+                    tag = f"bg{k}"
+                    handles = _regions(hipshm, c, [f"{tag}_in0", f"{tag}_in1", f"{tag}_out0", f"{tag}_out1"], 1024)
+                    try:
+                        for n in ("in0", "in1"):
+                            hipshm.set_shared_memory_region(handles[f"{tag}_{n}"], [serialize_byte_tensor(vals)])
+                        ins, outs = _request(g, 1, tag, [len(blob), len(blob)], 1024)
+                        while not stop.is_set():
+                            c.infer("simple_string", ins, outputs=outs)
+                    finally:
+                        _cleanup(hipshm, c, handles)
+            except Exception as e:  # noqa: BLE001
+                errors.append(f"{k}: {type(e).__name__}: {e}")
+
+        threads = [threading.Thread(target=load, args=(k,)) for k in range(4)]
+        for t in threads:
+            t.start()
+        try:
+            with g.InferenceServerClient(srv.grpc_url) as c:
+                before = _native_handled(srv.http_url)
+                for round_ in range(20):  # register, use, unregister while the others keep going
+                    tag = f"fg{round_}"
+                    handles = _regions(hipshm, c, [f"{tag}_in0", f"{tag}_in1", f"{tag}_out0", f"{tag}_out1"], 1024)
+                    try:
+                        for n in ("in0", "in1"):
+                            hipshm.set_shared_memory_region(handles[f"{tag}_{n}"], [serialize_byte_tensor(vals)])
+                        ins, outs = _request(g, 1, tag, [len(blob), len(blob)], 1024)
+                        res = c.infer("simple_string", ins, outputs=outs, request_id=f"r{round_}")
+                        assert res.get_response().id == f"r{round_}"
+                        assert res.get_output("OUTPUT1").shape == [1, 16]
+                        got = hipshm.get_contents_as_numpy(handles[f"{tag}_out0"], np.object_, [1, 16])
+                        assert [int(x) for x in got.reshape(-1)] == [14 * i for i in range(16)]
+                        if round_ == 5:  # refused by the device -> answered by the general path
+                            small_in, small_out = _request(g, 1, tag, [len(blob), len(blob)], 16)
+                            with pytest.raises(InferenceServerException, match="too small|should be at least"):
+                                c.infer("simple_string", small_in, outputs=small_out)
+                    finally:
+                        _cleanup(hipshm, c, handles)
+                assert _native_handled(srv.http_url) - before >= 20
+                stats = c.get_inference_statistics("simple_string", as_json=True)["model_stats"][0]
+                assert int(stats["inference_stats"]["success"]["count"]) >= 20
+        finally:
+            stop.set()
+            for t in threads:
+                t.join()
+        assert not errors, errors[:3]
+    finally:
+        srv.stop()

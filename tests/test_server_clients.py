@@ -650,6 +650,20 @@ def test_both_http_fronts_serve_the_same_surface(impl):
             np.testing.assert_array_equal(c.infer("custom_identity_int32", [inp]).as_numpy("OUTPUT0"), x)
             stats = c.get_inference_statistics("simple")["model_stats"][0]
             assert stats["inference_count"] >= 20
+            # the same counters in Prometheus text form
+            port = int(srv.http_url.rsplit(":", 1)[1])
+            out = _raw_http(port, b"GET /metrics HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n", expect_close=True)
+            head, _, text = out.partition(b"\r\n\r\n")
+            assert b"200 OK" in head and b"text/plain" in head.lower()
+            metrics = {}
+            for line in text.decode().splitlines():
+                if line and not line.startswith("#"):
+                    key, value = line.rsplit(" ", 1)
+                    metrics[key] = int(value)
+            assert metrics['nv_inference_request_success{model="simple",version="1"}'] >= 20
+            assert metrics['nv_inference_count{model="simple",version="1"}'] == stats["inference_count"]
+            native = metrics["tca_native_handled_total"] + metrics["tca_native_declined_total"]
+            assert native > 0 if impl == "native" else native == 0  # only the native front offers it requests
             c.unload_model("simple")
             assert not c.is_model_ready("simple")
 

@@ -235,6 +235,7 @@ class SimpleString(_DeviceBytesPath, Model):
     outputs = [TensorSpec("OUTPUT0", "BYTES", [16]), TensorSpec("OUTPUT1", "BYTES", [16])]
     device_op = 0
     device_outputs = ("OUTPUT0", "OUTPUT1")
+    native_kernel = "bytes_add_sub"  # device shared memory only; anything else runs below
 
     def execute(self, inputs, ctx):
         inputs = self._host_inputs(inputs)
@@ -259,6 +260,7 @@ class SimpleIdentity(_DeviceBytesPath, Model):
     outputs = [TensorSpec("OUTPUT0", "BYTES", [-1])]
     device_op = 1
     device_outputs = ("OUTPUT0",)
+    native_kernel = "bytes_identity"  # device shared memory only; anything else runs below
 
     def execute(self, inputs, ctx):
         return {"OUTPUT0": self._host_inputs(inputs)["INPUT0"]}

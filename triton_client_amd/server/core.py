@@ -25,6 +25,7 @@ from __future__ import annotations
 import base64
 import json
 import math
+import os
 import threading
 import time
 from dataclasses import dataclass, field
@@ -375,10 +376,22 @@ class DeviceShmRegistry(_Leased):
     (``on_close`` hooks) and only then closes the IPC mapping: the GPU never replays a graph
     or runs a copy on an unmapped address."""
 
+    native = None  # NativeExecutor that mirrors the registrations (name -> device address range)
+
     def __init__(self, drain_timeout_s=10.0):
         super().__init__(drain_timeout_s)
         self._views = {}  # (region, datatype, shape, offset) -> torch view; building one costs ~20 us
         self.on_close = []  # callables (base address, byte size): a mapping is about to be closed
+
+    def _mirror(self, name, entry):
+        """Tells the native executor about a region (its device BYTES path addresses it directly)."""
+        if self.native is None or entry.mapping.host_backed:
+            return
+        try:
+            self.native.register_device_region(name, int(entry.mapping.address), int(entry.byte_size),
+                                               int(entry.device_id))
+        except ValueError:
+            pass  # requests naming this region take the general path
 
     def tensor_view(self, name, mapping, datatype, shape, offset):
         """Torch view of a slice of a registered region, cached: requests of a
@@ -412,11 +425,17 @@ class DeviceShmRegistry(_Leased):
                     mapping = hipshm.open_shared_memory_region(name, raw_handle, byte_size, device_id)
             except Exception as e:
                 raise ServerError(f"failed to register device shared memory region '{name}': {e}", 400) from None
-            self._regions[name] = _DeviceRegion(device_id, byte_size, mapping)
+            entry = self._regions[name] = _DeviceRegion(device_id, byte_size, mapping)
+        self._mirror(name, entry)
 
     def unregister(self, name=""):
         from ..utils import hip_shared_memory as hipshm
 
+        if self.native is not None:
+            # first: no natively executed request may start on a region that is going away, and the
+            # queued ones finish before the mapping is closed
+            if not self.native.unregister_device_region(name or "", int(self.drain_timeout_s * 1000)):
+                self._raise_busy([name or "*"])
         with self._lock:
             removed, busy = self._drain(name)
             for n, _ in removed:
@@ -639,10 +658,40 @@ class InferenceCore:
                                          int(entry["offset"]), int(entry["byte_size"]))
             except ValueError:
                 pass
+        self._attach_device_bytes(executor)
         with self._lock:
             loaded = list(self._loaded.values())
         for lm in loaded:
             self._sync_native(lm)
+
+    def _attach_device_bytes(self, executor):
+        """With a GPU: gives the executor a device BYTES pipeline of its own (the kernels of
+        ``ops/bytes_pipe.py``, driven from its batch thread) and the device shared-memory
+        registrations, so BYTES models with a device path are answered without the interpreter."""
+        if self.gpu is None or os.environ.get("TCA_NATIVE_DEVICE_BYTES", "1") == "0":
+            return
+        try:
+            import ctypes
+
+            from ..ops import _device
+            from ..ops.bytes_pipe import BytesPipe, max_stream_bytes
+
+            max_requests, max_count = 64, 4096
+            pipe = BytesPipe(int(self.gpu), max_requests, max_count)
+            stream = _device.Stream(int(self.gpu))
+            lib = _device.lib()
+            address = lambda fn: ctypes.cast(fn, ctypes.c_void_p).value  # noqa: E731
+            executor.enable_device_bytes(address(lib.tca_bytes_pipe_submit), address(lib.tca_bytes_pipe_wait),
+                                         int(pipe._h.value), int(stream.handle), int(self.gpu), max_requests, max_count,
+                                         int(max_stream_bytes()))
+        except Exception:  # noqa: BLE001 - no HIP library / no device: the general path serves these models
+            return
+        self._native_pipe = (pipe, stream)  # alive as long as the executor's batch thread
+        self.devshm.native = executor
+        with self.devshm._lock:
+            entries = list(self.devshm._regions.items())
+        for name, entry in entries:
+            self.devshm._mirror(name, entry)
 
     def _sync_native(self, lm, present=True):
         executor = getattr(self, "native", None)
@@ -651,7 +700,8 @@ class InferenceCore:
         model = lm.model
         kernel = getattr(model, "native_kernel", None)
         eligible = present and kernel and model.device == "cpu" and not model.parameters \
-            and not getattr(model, "sequence", False) and (not model.decoupled or kernel == "repeat")
+            and not getattr(model, "sequence", False) and (not model.decoupled or kernel == "repeat") \
+            and (not kernel.startswith("bytes_") or self.devshm.native is not None)
         if not eligible:
             executor.remove_model(model.name)
             return
@@ -789,6 +839,47 @@ class InferenceCore:
                     continue
                 out.append(st.as_dict(n, v))
         return {"model_stats": out}
+
+    def metrics_text(self):
+        """Prometheus text exposition of the per-model counters (what a Triton server offers on its
+        metrics port, here under ``GET /metrics`` of the HTTP front), plus how many requests the
+        native execution path answered or handed on."""
+        rows = self.statistics()["model_stats"]
+        series = (
+            ("nv_inference_request_success", "counter", "Number of successful inference requests",
+             lambda r: r["inference_stats"]["success"]["count"]),
+            ("nv_inference_request_failure", "counter", "Number of failed inference requests",
+             lambda r: r["inference_stats"]["fail"]["count"]),
+            ("nv_inference_count", "counter", "Number of inferences performed (a batch of n counts n)",
+             lambda r: r["inference_count"]),
+            ("nv_inference_exec_count", "counter", "Number of model executions performed",
+             lambda r: r["execution_count"]),
+            ("nv_inference_request_duration_us", "counter", "Cumulative inference request duration in microseconds",
+             lambda r: r["inference_stats"]["success"]["ns"] // 1000),
+            ("nv_inference_queue_duration_us", "counter", "Cumulative inference queuing duration in microseconds",
+             lambda r: r["inference_stats"]["queue"]["ns"] // 1000),
+            ("nv_inference_compute_input_duration_us", "counter", "Cumulative compute input duration in microseconds",
+             lambda r: r["inference_stats"]["compute_input"]["ns"] // 1000),
+            ("nv_inference_compute_infer_duration_us", "counter", "Cumulative compute inference duration in microseconds",
+             lambda r: r["inference_stats"]["compute_infer"]["ns"] // 1000),
+            ("nv_inference_compute_output_duration_us", "counter", "Cumulative compute output duration in microseconds",
+             lambda r: r["inference_stats"]["compute_output"]["ns"] // 1000),
+        )
+        lines = []
+        for metric, kind, text, value in series:
+            lines.append(f"# HELP {metric} {text}")
+            lines.append(f"# TYPE {metric} {kind}")
+            for r in rows:
+                lines.append(f'{metric}{{model="{r["name"]}",version="{r["version"]}"}} {int(value(r))}')
+        executor = getattr(self, "native", None)
+        if executor is not None:
+            counters = executor.counters()
+            for key, text in (("handled", "Requests answered by the native execution path"),
+                              ("declined", "Requests the native execution path looked at and handed on")):
+                lines.append(f"# HELP tca_native_{key}_total {text}")
+                lines.append(f"# TYPE tca_native_{key}_total counter")
+                lines.append(f"tca_native_{key}_total {int(counters[key])}")
+        return "\n".join(lines) + "\n"
 
     # ----------------------------------------------------------- trace / log
     def update_trace(self, model_name, settings):
@@ -1329,3 +1420,10 @@ class InferenceCore:
             self.devshm.unregister()
         except Exception:
             pass
+        pipe = getattr(self, "_native_pipe", None)
+        if pipe is not None:
+            self.native.disable_device_bytes()  # its batch thread uses the pipeline released below
+            self.devshm.native = None
+            self._native_pipe = None
+            pipe[0].close()
+            pipe[1].close()

@@ -204,6 +204,8 @@ class Router:
             return ok(core.server_metadata())
         if path == "v2/models/stats":
             return ok(core.statistics())
+        if path == "metrics":
+            return 200, {"Content-Type": "text/plain; version=0.0.4; charset=utf-8"}, [core.metrics_text().encode()]
         if path == "v2/repository/index":
             ready = bool(json.loads(body).get("ready", False)) if body.strip() else False
             return ok(core.repository_index(ready))
