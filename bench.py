@@ -423,7 +423,8 @@ def measure_secondary(args, device, dist):
     """The other configurations of the benchmark set, each on this rank's own server and GPU:
     `simple` over HTTP + system shared memory, `simple` over gRPC with tensors on the wire,
     `simple_string` (BYTES) over gRPC + HIP shared memory, `repeat_int32` (decoupled, 16 responses
-    per request) over gRPC streams.  Closed loop at concurrency 16, two 1 s windows each; with
+    per request) and `simple_sequence` (stateful, sequences of 20 requests) over gRPC streams.
+    Closed loop at concurrency 16, two 1 s windows each; with
     several ranks the throughputs are summed over the GPUs and the latencies are the worst rank's."""
     import contextlib
 
@@ -432,8 +433,8 @@ def measure_secondary(args, device, dist):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from secondary_bench import run_configs
 
-    names = ["simple_http_sysshm", "simple_grpc_wire", "string_grpc_hipshm", "decoupled_stream"]
-    rates, lats, error = [0.0] * 4, [0.0] * 8, None
+    names = ["simple_http_sysshm", "simple_grpc_wire", "string_grpc_hipshm", "decoupled_stream", "sequence_stream"]
+    rates, lats, error = [0.0] * len(names), [0.0] * (2 * len(names)), None
     try:
         with contextlib.redirect_stdout(sys.stderr):  # the analyzer reports on stdout; ours carries one JSON line
             lines = {line["config"]: line for line in run_configs(gpu=device, window_ms=1000)}
@@ -450,7 +451,7 @@ def measure_secondary(args, device, dist):
         rates = [float(v) for v in t.tolist()]
         t = torch.tensor(lats + [-ok], device=args.reduce_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        lats, ok = [float(v) for v in t[:8].tolist()], -float(t[8].item())
+        lats, ok = [float(v) for v in t[:-1].tolist()], -float(t[-1].item())
     if ok < 1.0:
         return {"error": error or "a configuration failed on another rank"}
     out = {}
@@ -459,6 +460,7 @@ def measure_secondary(args, device, dist):
         out[name] = {key: round(rates[i], 1), "p50_latency_us": round(lats[2 * i], 1),
                      "p99_latency_us": round(lats[2 * i + 1], 1), "concurrency_per_gpu": 16}
     out["decoupled_stream"]["responses_per_request"] = 16
+    out["sequence_stream"]["sequence_length"] = 20
     return out
 
 

@@ -6,6 +6,7 @@
 //   ex.register_region(name, key, offset, byte_size) / ex.unregister_region(name)   # "" = all
 //   ex.take_stats(name) -> None | {"requests", "inferences", "queue_ns", "last_ms", "by_batch": {b: (count, in, infer, out)}}
 //   ex.set_enabled(flag); ex.counters() -> {"handled", "declined"}
+//   ex.sequence_step(name, id, start, end) -> bool; ex.open_sequences(name) -> int
 //   ex.enable_device_bytes(submit_address, wait_address, pipe, stream, device, max_requests, max_count, max_stream_bytes)
 //   ex.disable_device_bytes(); ex.quiesce()
 //   ex.register_device_region(name, address, byte_size, device) / ex.unregister_device_region(name, timeout_ms) -> bool
@@ -241,6 +242,22 @@ PyObject* UnregisterDeviceRegion(PyObject* self_obj, PyObject* args) {
   return PyBool_FromLong(idle ? 1 : 0);
 }
 
+PyObject* SequenceStep(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = nullptr;
+  unsigned long long id = 0;
+  int start = 0, end = 0;
+  if (!PyArg_ParseTuple(args, "sKpp", &name, &id, &start, &end)) return nullptr;
+  return PyBool_FromLong((*self->ex)->SequenceStep(name, id, start != 0, end != 0) ? 1 : 0);
+}
+
+PyObject* OpenSequences(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = nullptr;
+  if (!PyArg_ParseTuple(args, "s", &name)) return nullptr;
+  return PyLong_FromLong((*self->ex)->OpenSequences(name));
+}
+
 PyMethodDef kMethods[] = {
     {"set_model", SetModel, METH_VARARGS, "set_model(name, version, max_batch, inputs, outputs, kernel)"},
     {"remove_model", RemoveModel, METH_VARARGS, "remove_model(name)"},
@@ -249,6 +266,9 @@ PyMethodDef kMethods[] = {
     {"take_stats", TakeStats, METH_VARARGS, "take_stats(name): statistics accumulated since the last call, or None"},
     {"set_enabled", SetEnabled, METH_VARARGS, "set_enabled(flag)"},
     {"counters", Counters, METH_NOARGS, "requests handled natively / looked at and handed on"},
+    {"sequence_step", SequenceStep, METH_VARARGS,
+     "sequence_step(name, id, start, end) -> False when the sequence was never started (or the model has no sequence kernel)"},
+    {"open_sequences", OpenSequences, METH_VARARGS, "open_sequences(name) -> sequences started and not ended (-1: no such model)"},
     {"enable_device_bytes", EnableDeviceBytes, METH_VARARGS,
      "enable_device_bytes(submit_address, wait_address, pipe, stream, device, max_requests, max_count, max_stream_bytes)"},
     {"disable_device_bytes", DisableDeviceBytes, METH_NOARGS, "answers what is queued and stops the batch thread"},

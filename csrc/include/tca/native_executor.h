@@ -15,6 +15,12 @@
 // "identity" (OUTPUT0 = INPUT0) and, over gRPC streams, the decoupled "repeat" (one
 // response per input element, as `src/python/examples/simple_grpc_custom_repeat.py` uses).
 //
+// Stateful models ("sequence" on `simple_sequence`: OUTPUT = INPUT, + 1 on the first request of a
+// sequence; "dyna_sequence" on `simple_dyna_sequence`: the same plus the correlation id on the last
+// one; `src/python/examples/simple_grpc_sequence_stream_infer_client.py` drives both): the table of
+// open sequences lives here and the Python core consults the same table (SequenceStep), so a
+// sequence may mix requests answered here and requests that took the general path.
+//
 // BYTES models whose tensors stay in device shared memory ("bytes_add_sub" on `simple_string`,
 // "bytes_identity" on `simple_identity`; the reference drives them through
 // `src/python/examples/simple_grpc_cudashm_string_client.py`-style callers): the request is
@@ -38,6 +44,7 @@
 #include <shared_mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -120,6 +127,12 @@ class NativeExecutor {
   bool TryHttp(const std::string& model, const std::string& version, const std::string& body, int64_t header_length,
                HeaderList* headers, std::vector<std::string>* parts);
 
+  // One request of sequence `id` (numeric correlation id, not 0) of a model with a sequence kernel: opens the
+  // sequence on `start`, closes it on `end`.  False: no such model, or the sequence was never started.
+  bool SequenceStep(const std::string& name, uint64_t id, bool start, bool end);
+  // Sequences of `name` that have been started and not ended (-1: no such model).
+  long OpenSequences(const std::string& name);
+
   // Moves the statistics accumulated for `name` since the last call into `out`; false if there are none.
   bool TakeStats(const std::string& name, Stats* out);
   uint64_t Handled() const { return handled_.load(); }
@@ -139,6 +152,9 @@ class NativeExecutor {
     size_t itemsize = 0;
     std::mutex stats_mu;
     Stats stats;
+    std::mutex seq_mu;
+    std::unordered_set<uint64_t> open_sequences;
+    bool Step(uint64_t id, bool start, bool end);
   };
   struct DeviceRegion {
     uint64_t address = 0, size = 0;

@@ -18,6 +18,10 @@
 //       --streaming          gRPC: requests travel on one bidirectional stream per connection
 //                            (decoupled models: any number of responses per request; a request
 //                            is complete at its final response).  Reports responses/sec as well.
+//       --sequence-length L  stateful models: every slot sends sequences of L requests (start flag on
+//                            the first, end flag on the last, one correlation id per sequence; ids
+//                            count up from --sequence-id-base, default 1); a slot whose request
+//                            fails starts a new sequence.  A timed run ends every sequence it began.
 //       -b batch (only scales the reported infer/sec)
 #include <algorithm>
 #include <atomic>
@@ -66,6 +70,9 @@ struct Slot {
   std::vector<tc::InferInput*> in_ptrs;
   std::vector<const tc::InferRequestedOutput*> out_ptrs;
   uint64_t t0 = 0;
+  // sequences (--sequence-length): position of the request in flight and the sequences this slot has begun
+  int seq_pos = 0;
+  uint64_t seq_no = 0;
 };
 
 }  // namespace
@@ -75,6 +82,8 @@ int main(int argc, char** argv) {
   int concurrency = 1, batch = 1, connections = 1;
   long long count = 0, warmup_count = 0;
   bool wait_go = false, streaming = false;
+  int sequence_length = 0;
+  uint64_t sequence_id_base = 1;
   double duration = 5.0, warmup = 1.0;
   std::vector<std::string> shapes, shm_in, shm_out;
   std::string trace_path;
@@ -90,6 +99,8 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--connections")) connections = std::max(1, std::atoi(next()));
     else if (!std::strcmp(argv[i], "--trace")) trace_path = next();
     else if (!std::strcmp(argv[i], "--streaming")) streaming = true;
+    else if (!std::strcmp(argv[i], "--sequence-length")) sequence_length = std::max(0, std::atoi(next()));
+    else if (!std::strcmp(argv[i], "--sequence-id-base")) sequence_id_base = std::max(1ull, std::strtoull(next(), nullptr, 10));
     else if (!std::strcmp(argv[i], "-c")) concurrency = std::atoi(next());
     else if (!std::strcmp(argv[i], "-b")) batch = std::atoi(next());
     else if (!std::strcmp(argv[i], "-d")) duration = std::atof(next());
@@ -220,8 +231,15 @@ int main(int argc, char** argv) {
         latencies.push_back(t1 - slots[s]->t0);
       }
       if (record && tracing) trace_rows.push_back({slots[s]->t0, t1 - slots[s]->t0, s, status.IsOk()});
+      if (sequence_length > 0) {
+        Slot* slot = slots[s].get();
+        if (!status.IsOk() || ++slot->seq_pos == sequence_length) {  // next request opens a new sequence
+          slot->seq_pos = 0;
+          ++slot->seq_no;
+        }
+      }
       if (open_ended) {
-        again = !stopping;
+        again = !stopping || (sequence_length > 0 && slots[s]->seq_pos != 0 && status.IsOk());  // a sequence is ended, not dropped
       } else {
         --to_finish;
         if (to_issue > 0) {
@@ -260,8 +278,13 @@ int main(int argc, char** argv) {
     Slot* slot = slots[s].get();
     slot->t0 = NowNs();
     tca::Error se;
+    tc::InferOptions per_request = options;
+    if (sequence_length > 0) {
+      per_request.sequence_id_ = sequence_id_base + slot->seq_no * static_cast<uint64_t>(concurrency) + static_cast<uint64_t>(s);
+      per_request.sequence_start_ = slot->seq_pos == 0;
+      per_request.sequence_end_ = slot->seq_pos == sequence_length - 1;
+    }
     if (streaming) {
-      tc::InferOptions per_request = options;
       per_request.request_id_ = std::to_string(s);
       per_request.triton_enable_empty_final_response_ = true;
       se = grpc_clients[s % grpc_clients.size()]->AsyncStreamInfer(per_request, slot->in_ptrs, slot->out_ptrs);
@@ -272,8 +295,8 @@ int main(int argc, char** argv) {
         delete r;
         complete(s, status, t1);
       };
-      se = use_grpc ? grpc_clients[s % grpc_clients.size()]->AsyncInfer(on_done, options, slot->in_ptrs, slot->out_ptrs)
-                    : client->AsyncInfer(on_done, options, slot->in_ptrs, slot->out_ptrs);
+      se = use_grpc ? grpc_clients[s % grpc_clients.size()]->AsyncInfer(on_done, per_request, slot->in_ptrs, slot->out_ptrs)
+                    : client->AsyncInfer(on_done, per_request, slot->in_ptrs, slot->out_ptrs);
     }
     if (!se.IsOk()) {
       std::lock_guard<std::mutex> lk(mu);

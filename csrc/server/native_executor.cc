@@ -17,7 +17,7 @@ namespace tca {
 namespace server {
 namespace {
 
-enum Kernel { kAddSub = 1, kIdentity = 2, kRepeat = 3, kBytesAddSub = 4, kBytesIdentity = 5 };
+enum Kernel { kAddSub = 1, kIdentity = 2, kRepeat = 3, kBytesAddSub = 4, kBytesIdentity = 5, kSequence = 6, kDynaSequence = 7 };
 
 size_t ItemSize(const std::string& dt) {
   if (dt == "INT8" || dt == "UINT8" || dt == "BOOL") return 1;
@@ -93,6 +93,9 @@ struct NativeExecutor::Request {
   };
   std::string model, version, id;
   bool want_final = false;  // streams: triton_enable_empty_final_response
+  bool has_sequence = false;  // any of sequence_id / sequence_start / sequence_end was given
+  uint64_t sequence_id = 0;
+  bool sequence_start = false, sequence_end = false;
   std::vector<Input> inputs;
   std::vector<Output> outputs;  // empty = all
   std::vector<Result> results;
@@ -141,6 +144,16 @@ Error NativeExecutor::SetModel(const ModelSpec& spec) {
     for (const auto& t : spec.outputs)
       if (t.datatype != "BYTES") return Error(spec.kernel + " produces BYTES tensors");
     m->kernel = arity == 2 ? kBytesAddSub : kBytesIdentity;
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    models_[spec.name] = std::move(m);
+    return Error::Success();
+  } else if (spec.kernel == "sequence" || spec.kernel == "dyna_sequence") {
+    if (spec.inputs.size() != 1 || spec.outputs.size() != 1 || spec.inputs[0].datatype != "INT32" ||
+        spec.outputs[0].datatype != "INT32" || spec.inputs[0].dims != std::vector<int64_t>{1} ||
+        spec.outputs[0].dims != std::vector<int64_t>{1} || spec.max_batch != 1)
+      return Error(spec.kernel + " needs one INT32 [1] input and output and a batch limit of 1");
+    m->kernel = spec.kernel == "sequence" ? kSequence : kDynaSequence;
+    m->itemsize = 4;
     std::unique_lock<std::shared_mutex> lk(mu_);
     models_[spec.name] = std::move(m);
     return Error::Success();
@@ -208,6 +221,32 @@ std::shared_ptr<NativeExecutor::Model> NativeExecutor::FindModel(const std::stri
   return it->second;
 }
 
+bool NativeExecutor::Model::Step(uint64_t id, bool start, bool end) {
+  std::lock_guard<std::mutex> lk(seq_mu);
+  if (start) {
+    if (!end) open_sequences.insert(id);
+    else open_sequences.erase(id);
+    return true;
+  }
+  auto it = open_sequences.find(id);
+  if (it == open_sequences.end()) return false;  // the first request of a sequence carries the start flag
+  if (end) open_sequences.erase(it);
+  return true;
+}
+
+bool NativeExecutor::SequenceStep(const std::string& name, uint64_t id, bool start, bool end) {
+  std::shared_ptr<Model> m = FindModel(name, std::string());
+  if (!m || (m->kernel != kSequence && m->kernel != kDynaSequence) || id == 0) return false;
+  return m->Step(id, start, end);
+}
+
+long NativeExecutor::OpenSequences(const std::string& name) {
+  std::shared_ptr<Model> m = FindModel(name, std::string());
+  if (!m) return -1;
+  std::lock_guard<std::mutex> lk(m->seq_mu);
+  return static_cast<long>(m->open_sequences.size());
+}
+
 bool NativeExecutor::TakeStats(const std::string& name, Stats* out) {
   std::shared_ptr<Model> m;
   {
@@ -228,7 +267,15 @@ bool NativeExecutor::TakeStats(const std::string& name, Stats* out) {
 bool NativeExecutor::Run(Request* req, const std::shared_ptr<Model>& model) {
   const ModelSpec& spec = model->spec;
   const uint64_t t0 = NowNs();
-  if (model->kernel != kAddSub && model->kernel != kIdentity) return false;
+  const bool stateful = model->kernel == kSequence || model->kernel == kDynaSequence;
+  if (model->kernel != kAddSub && model->kernel != kIdentity && !stateful) return false;
+  if (stateful) {
+    if (!req->has_sequence || req->sequence_id == 0) return false;  // the general path words the refusal
+    // the last request of a dyna sequence adds the id as a 32-bit integer: larger ids are the general path's to refuse
+    if (model->kernel == kDynaSequence && req->sequence_end && req->sequence_id > 0x7fffffffull) return false;
+  } else if (req->has_sequence) {
+    return false;
+  }
   if (req->inputs.size() != spec.inputs.size()) return false;
   const Request::Input* ordered[2] = {nullptr, nullptr};
   int64_t batch = 0;
@@ -321,7 +368,17 @@ bool NativeExecutor::Run(Request* req, const std::shared_ptr<Model>& model) {
   // `results` does not grow any more, but the pointers into its strings were taken while it did:
   // strings of this size live on the heap, and reserve() above keeps the vector in place
   const uint64_t t1 = NowNs();
-  if (model->kernel == kAddSub) {
+  if (stateful) {
+    // everything has been validated: from here on the request is answered, so the table may move
+    if (!model->Step(req->sequence_id, req->sequence_start, req->sequence_end)) return false;
+    if (dest[0] != nullptr) {
+      uint32_t v;
+      std::memcpy(&v, ordered[0]->data, 4);
+      if (req->sequence_start) v += 1u;
+      if (model->kernel == kDynaSequence && req->sequence_end) v += static_cast<uint32_t>(req->sequence_id);
+      std::memcpy(dest[0], &v, 4);
+    }
+  } else if (model->kernel == kAddSub) {
     if (!AddSub(spec.inputs[0].datatype, ordered[0]->data, ordered[1]->data, dest[0], dest[1], count)) return false;
   } else {
     if (dest[0] != nullptr) std::memcpy(dest[0], ordered[0]->data, nbytes);
@@ -419,8 +476,9 @@ bool NativeExecutor::ParseGrpc(const std::string& request, bool stream, Request*
       if (!r.String(&req.version)) return false;
     } else if (f == 3 && wt == pb::kLen) {
       if (!r.String(&req.id)) return false;
-    } else if (f == 4 && wt == pb::kLen && stream) {
-      // map<string, InferParameter> entry: only the final-response switch (a bool) is ours
+    } else if (f == 4 && wt == pb::kLen) {
+      // map<string, InferParameter> entry.  Understood: the sequence controls (numeric correlation id, start and
+      // end flags) and, on streams, the final-response switch; any other key sends the request down the general path.
       const uint8_t* d;
       size_t n;
       if (!r.Len(&d, &n)) return false;
@@ -438,21 +496,40 @@ bool NativeExecutor::ParseGrpc(const std::string& request, bool stream, Request*
           return false;
         }
       }
-      if (e.Failed() || key != "triton_enable_empty_final_response") return false;
+      if (e.Failed()) return false;
+      // InferParameter: bool_param = 1, int64_param = 2, uint64_param = 5 (strings and doubles are not ours)
+      bool is_bool = false, is_int = false, flag = false;
+      uint64_t number = 0;
       pb::Reader p(vd, vn);
-      bool seen = false;
       while (p.Next(&ef, &ewt)) {
         uint64_t u;
-        if (ef == 1 && ewt == pb::kVarint && p.Varint(&u)) {
-          req.want_final = u != 0;
-          seen = true;
+        if (ewt != pb::kVarint || !p.Varint(&u)) return false;
+        if (ef == 1) {
+          is_bool = true;
+          flag = u != 0;
+        } else if (ef == 2 || ef == 5) {
+          is_int = true;
+          number = u;
         } else {
           return false;
         }
       }
-      if (p.Failed() || (!seen && vn != 0)) return false;
-    } else if (f == 4) {
-      return false;  // request parameters (sequences, priorities, timeouts...): general path
+      if (p.Failed() || is_bool == is_int) return false;  // exactly one value (an absent one reads as neither)
+      if (key == "triton_enable_empty_final_response" && is_bool && stream) {
+        req.want_final = flag;
+      } else if (key == "sequence_id" && is_int) {
+        if (number >> 63) return false;  // a negative int64: the general path refuses it
+        req.sequence_id = number;
+        req.has_sequence = true;
+      } else if (key == "sequence_start" && is_bool) {
+        req.sequence_start = flag;
+        req.has_sequence = true;
+      } else if (key == "sequence_end" && is_bool) {
+        req.sequence_end = flag;
+        req.has_sequence = true;
+      } else {
+        return false;
+      }
     } else if (f == 5 && wt == pb::kLen) {
       const uint8_t* d;
       size_t n;
@@ -616,6 +693,7 @@ bool NativeExecutor::TryGrpc(const std::string& request, std::string* response) 
 // The decoupled kernel: IN[n], DELAY[n] (all zero here), WAIT[1] (zero) -> n responses OUT = [IN[i]], IDX = [i].
 bool NativeExecutor::RunRepeat(Request* req, const std::shared_ptr<Model>& model, std::vector<std::string>* responses) {
   const Request::Input *in = nullptr, *delay = nullptr, *wait = nullptr;
+  if (req->has_sequence) return false;
   for (const auto& t : req->inputs) {
     const Request::Input** slot = t.name == "IN" ? &in : t.name == "DELAY" ? &delay : t.name == "WAIT" ? &wait : nullptr;
     if (slot == nullptr || *slot != nullptr || t.shm.set || !t.has_data || t.shape.size() != 1 || t.shape[0] < 0) return false;
@@ -804,6 +882,7 @@ bool NativeExecutor::PrepareDeviceJob(Request* req, const std::shared_ptr<Model>
   const ModelSpec& spec = model->spec;
   job->t0 = NowNs();
   const size_t arity = spec.inputs.size();
+  if (req->has_sequence) return false;
   if (req->inputs.size() != arity || req->outputs.size() != arity) return false;  // outputs must name their regions
   const Request::Input* ordered[2] = {nullptr, nullptr};
   const size_t lead = spec.max_batch > 0 ? 1 : 0;
@@ -1071,8 +1150,21 @@ bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& v
       outputs = &kv.second;
     } else if (kv.first == "parameters" && kv.second.IsObject()) {
       for (const auto& p : kv.second.Members()) {
-        if (p.first == "binary_data_output" && p.second.IsBool()) default_binary = p.second.AsBool();
-        else return false;
+        if (p.first == "binary_data_output" && p.second.IsBool()) {
+          default_binary = p.second.AsBool();
+        } else if (p.first == "sequence_id" && p.second.IsNumber() && p.second.AsInt() >= 0 &&
+                   static_cast<double>(p.second.AsInt()) == p.second.AsDouble()) {
+          req.sequence_id = static_cast<uint64_t>(p.second.AsInt());
+          req.has_sequence = true;
+        } else if (p.first == "sequence_start" && p.second.IsBool()) {
+          req.sequence_start = p.second.AsBool();
+          req.has_sequence = true;
+        } else if (p.first == "sequence_end" && p.second.IsBool()) {
+          req.sequence_end = p.second.AsBool();
+          req.has_sequence = true;
+        } else {
+          return false;
+        }
       }
     } else {
       return false;

@@ -377,6 +377,81 @@ void DeviceBytesPath() {
   if (answered.load() == 0 || refused.load() == 0) Fail("device bytes: nothing was answered or nothing refused");
 }
 
+// Stateful kernel: threads run whole sequences through the gRPC path while another one walks sequences of its
+// own through SequenceStep (what the Python core does for requests that took the general path).
+std::string SequenceRequest(const char* model, int32_t value, uint64_t id, bool start, bool end) {
+  std::string out;
+  pb::Writer w(&out);
+  w.String(1, model);
+  auto param = [&](const char* key, bool is_bool, uint64_t v) {
+    std::string entry, value_msg;
+    pb::Writer ew(&entry), vw(&value_msg);
+    if (is_bool) vw.Bool(1, v != 0);
+    else vw.Int(2, static_cast<int64_t>(v));
+    ew.String(1, key);
+    ew.Message(2, value_msg);
+    w.Message(4, entry);
+  };
+  param("sequence_id", false, id);
+  if (start) param("sequence_start", true, 1);
+  if (end) param("sequence_end", true, 1);
+  std::string t, shape;
+  pb::Writer tw(&t), sw(&shape);
+  tw.String(1, "INPUT");
+  tw.String(2, "INT32");
+  sw.Varint(1);
+  sw.Varint(1);
+  tw.Message(3, shape);
+  w.Message(5, t);
+  w.Bytes(7, &value, 4);
+  return out;
+}
+
+void SequencePath() {
+  NativeExecutor ex;
+  NativeExecutor::ModelSpec m;
+  m.name = "simple_dyna_sequence";
+  m.version = "1";
+  m.max_batch = 1;
+  m.kernel = "dyna_sequence";
+  m.inputs = {{"INPUT", "INT32", {1}}};
+  m.outputs = {{"OUTPUT", "INT32", {1}}};
+  if (!ex.SetModel(m).IsOk()) Fail("sequence: registering the model");
+  std::string response;
+  if (ex.TryGrpc(SequenceRequest("simple_dyna_sequence", 1, 5, false, false), &response)) Fail("sequence: answered without a start");
+  if (ex.TryGrpc(SequenceRequest("simple_dyna_sequence", 1, 0, true, false), &response)) Fail("sequence: id 0 accepted");
+  std::vector<std::thread> threads;
+  std::atomic<long> steps{0};
+  for (int t = 0; t < 4; ++t) {
+    threads.emplace_back([&, t] {
+      std::string resp;
+      for (int round = 0; round < 2000; ++round) {
+        const uint64_t id = 1000 + static_cast<uint64_t>(t) * 100000 + static_cast<uint64_t>(round);
+        for (int k = 0; k < 4; ++k) {
+          const bool start = k == 0, end = k == 3;
+          if (t == 3) {  // the general path's view of the same table
+            if (!ex.SequenceStep("simple_dyna_sequence", id, start, end)) Fail("sequence: step refused");
+            continue;
+          }
+          if (!ex.TryGrpc(SequenceRequest("simple_dyna_sequence", 10 * k, id, start, end), &resp)) {
+            Fail("sequence: request declined");
+            continue;
+          }
+          auto raws = RawOutputs(resp);
+          int32_t got = 0;
+          if (raws.size() == 1 && raws[0].size() == 4) std::memcpy(&got, raws[0].data(), 4);
+          const int32_t want = 10 * k + (start ? 1 : 0) + (end ? static_cast<int32_t>(id) : 0);
+          if (got != want) Fail("sequence: wrong value");
+          ++steps;
+        }
+      }
+    });
+  }
+  for (auto& t : threads) t.join();
+  if (ex.OpenSequences("simple_dyna_sequence") != 0) Fail("sequence: sequences left open");
+  std::cout << "sequences: " << steps.load() << " requests answered" << std::endl;
+}
+
 }  // namespace
 
 int main() {
@@ -533,6 +608,7 @@ int main() {
   munmap(mem, 4096);
   shm_unlink(key);
   DeviceBytesPath();
+  SequencePath();
   std::cout << "answered " << answered.load() << ", declined " << declined.load() << ", statistics collected for "
             << collected.load() << ", failures " << g_failures.load() << std::endl;
   if (g_failures.load() != 0 || answered.load() == 0) return 1;

@@ -15,7 +15,8 @@ from tritonclient.utils import InferenceServerException
 def servers():
     from triton_client_amd.server import Server
 
-    models = ["simple", "simple_int8", "simple_string", "custom_identity_int32", "repeat_int32"]
+    models = ["simple", "simple_int8", "simple_string", "custom_identity_int32", "repeat_int32", "simple_sequence",
+              "simple_dyna_sequence"]
     on = Server(models=models, native_exec=True, model_control="explicit").start()
     off = Server(models=models, native_exec=False, model_control="explicit").start()
     for srv in (on, off):
@@ -309,3 +310,79 @@ def test_ordinary_models_over_streams(servers):
     assert rows[0][0][2] is True and rows[0][1][2] is None
     with grpcclient.InferenceServerClient(on.grpc_url) as c:
         assert c.get_inference_statistics("simple").model_stats[0].inference_count - s0 == 12
+
+
+def _sequence_request(mod, value):
+    return [mod.InferInput("INPUT", [1, 1], "INT32").set_data_from_numpy(np.array([[value]], dtype=np.int32))]
+
+
+@pytest.mark.parametrize("protocol", ["grpc", "http"])
+def test_stateful_models_run_natively_and_match(servers, protocol):
+    """Sequences (numeric correlation ids) on `simple_sequence` / `simple_dyna_sequence`: start adds one,
+    the dyna model adds the id on the last request, and both servers answer the same - errors included."""
+    on, off = servers
+    mod = grpcclient if protocol == "grpc" else httpclient
+    before = _handled(on)
+    transcripts = []
+    for srv in (on, off):
+        rows = []
+        with mod.InferenceServerClient(srv.grpc_url if protocol == "grpc" else srv.http_url) as c:
+            for model, seq in (("simple_sequence", 1001), ("simple_dyna_sequence", 1002)):
+                for k, value in enumerate((10, 20, 2**31 - 1, -5)):
+                    r = c.infer(model, _sequence_request(mod, value), sequence_id=seq, sequence_start=(k == 0),
+                                sequence_end=(k == 3), request_id=f"{model}-{k}")
+                    resp = r.get_response()
+                    rows.append((resp.id if protocol == "grpc" else resp["id"], int(r.as_numpy("OUTPUT")[0, 0])))
+                # a one-request sequence, and a sequence that is opened twice
+                r = c.infer(model, _sequence_request(mod, 7), sequence_id=seq + 10, sequence_start=True, sequence_end=True)
+                rows.append(int(r.as_numpy("OUTPUT")[0, 0]))
+                for _ in range(2):
+                    r = c.infer(model, _sequence_request(mod, 1), sequence_id=seq + 20, sequence_start=True)
+                    rows.append(int(r.as_numpy("OUTPUT")[0, 0]))
+                c.infer(model, _sequence_request(mod, 1), sequence_id=seq + 20, sequence_end=True)
+                # no start flag, no id, an ended sequence: refused in the same words
+                for kwargs in ({"sequence_id": seq + 30}, {}, {"sequence_id": seq, "sequence_end": True}):
+                    with pytest.raises(InferenceServerException) as err:
+                        c.infer(model, _sequence_request(mod, 1), **kwargs)
+                    rows.append(str(err.value))
+                # string correlation ids stay with the general path and have a namespace of their own
+                r = c.infer(model, _sequence_request(mod, 3), sequence_id="77" if model.endswith("dyna_sequence") else "s",
+                            sequence_start=True, sequence_end=True)
+                rows.append(int(r.as_numpy("OUTPUT")[0, 0]))
+        transcripts.append(rows)
+    assert transcripts[0] == transcripts[1]
+    rows = transcripts[0]
+    assert [v for _, v in rows[:4]] == [11, 20, 2**31 - 1, -5]
+    assert "START" in rows[7]
+    assert _handled(on) - before == 2 * (4 + 1 + 3)  # everything but the refusals and the string ids
+    assert on._native.open_sequences("simple_sequence") == 0 and on._native.open_sequences("simple_dyna_sequence") == 0
+    dyna = transcripts[0][len(rows) // 2:]
+    assert [v for _, v in dyna[:4]] == [11, 20, 2**31 - 1, np.int32(-5 + 1002)]
+
+
+def test_sequences_over_streams_and_mixed_paths(servers):
+    """A sequence whose requests alternate between the native path and the general one (here: a request
+    parameter the native path does not know) stays one sequence; streams carry sequences too."""
+    on, off = servers
+    outs = []
+    for srv in (on, off):
+        with grpcclient.InferenceServerClient(srv.grpc_url) as c:
+            got = []
+            for k in range(4):
+                extra = {"parameters": {"note": "x"}} if k % 2 else {}
+                r = c.infer("simple_sequence", _sequence_request(grpcclient, k), sequence_id=555, sequence_start=(k == 0),
+                            sequence_end=(k == 3), **extra)
+                got.append(int(r.as_numpy("OUTPUT")[0, 0]))
+            outs.append(got)
+
+        def send(c):
+            for k in range(6):
+                c.async_stream_infer("simple_dyna_sequence", _sequence_request(grpcclient, 100 + k), sequence_id=9,
+                                     sequence_start=(k == 0), sequence_end=(k == 5), request_id=str(k))
+
+        pairs = _stream_collect(srv.grpc_url, send, 6)
+        assert all(e is None for _, e in pairs)
+        outs.append(sorted((int(r.get_response().id), int(r.as_numpy("OUTPUT")[0, 0])) for r, _ in pairs))
+    assert outs[0] == outs[2] == [1, 1, 2, 3]
+    assert outs[1] == outs[3] == [(0, 101), (1, 101), (2, 102), (3, 103), (4, 104), (5, 114)]
+    assert on._native.open_sequences("simple_sequence") == 0

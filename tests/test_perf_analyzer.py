@@ -128,6 +128,43 @@ def test_native_streaming_drives_a_decoupled_model(two_servers):
         _run(["-m", "repeat_int32", "--shape", "IN:5", "--shape", "DELAY:5", "--shape", "WAIT:1"] + base)
 
 
+@pytest.mark.parametrize("mode", ["python-grpc", "python-http", "native-grpc", "native-http", "native-stream"])
+def test_stateful_models_are_driven_with_sequences(two_servers, mode):
+    """A model with a sequence batcher: every slot sends sequences (start flag, correlation id, end
+    flag) - by default 20 requests long, `--sequence-length` changes it - and no request fails, which
+    it would if a flag or an id were wrong (the model refuses a request without a started sequence)."""
+    from triton_client_amd import _build
+
+    _build.build_cpp()
+    a, _ = two_servers
+    proto = "http" if mode.endswith("http") else "grpc"
+    argv = ["-m", "simple_sequence", "-u", a.http_url if proto == "http" else a.grpc_url, "-i", proto,
+            "--concurrency-range", "3", "-p", "200", "--stability-windows", "2", "--warmup-ms", "100", "-r", "4", "-s",
+            "50", "--worker-processes", "1"]
+    if mode.startswith("native"):
+        argv.append("--native")
+    if mode == "native-stream":
+        argv.append("--streaming")
+    if mode in ("python-http", "native-grpc"):
+        argv += ["--sequence-length", "3"]
+    import tritonclient.grpc as g
+
+    def counts():
+        with g.InferenceServerClient(a.grpc_url) as c:
+            st = c.get_inference_statistics("simple_sequence", as_json=True)["model_stats"][0]["inference_stats"]
+            return int(st["success"].get("count", 0)), int(st["fail"].get("count", 0))
+
+    ok0, fail0 = counts()
+    rows = _run(argv)
+    ok1, fail1 = counts()
+    assert rows[0]["errors"] == 0 and rows[0]["requests"] > 10
+    assert fail1 == fail0 and ok1 - ok0 >= rows[0]["requests"]
+    # a timed native run ends the sequences it began: the server holds no state for them afterwards
+    if mode.startswith("native"):
+        assert not a.core._loaded["simple_sequence"].sequences
+        assert a._native is None or a._native.open_sequences("simple_sequence") == 0
+
+
 def test_native_mode_rejects_open_loop(two_servers):
     a, _ = two_servers
     with pytest.raises(SystemExit):

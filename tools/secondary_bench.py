@@ -5,6 +5,8 @@
   simple_grpc_wire        the same model over gRPC with tensors on the wire
   string_grpc_hipshm      `simple_string` (BYTES tensors) over gRPC with HIP shared memory
   decoupled_stream        `repeat_int32` (16 responses per request) over bidirectional streams: responses/sec
+  sequence_stream         `simple_sequence` (stateful: sequences of 20 requests, one correlation id each) over
+                          bidirectional streams
 """
 import argparse
 import json
@@ -15,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run_configs(gpu=None, window_ms=1000, emit=None):
-    """Runs the four configurations against one freshly spawned server; returns a list of dicts."""
+    """Runs the configurations against one freshly spawned server; returns a list of dicts."""
     from triton_client_amd.perf import main as perf
     from triton_client_amd.server import spawn_server
 
@@ -26,7 +28,7 @@ def run_configs(gpu=None, window_ms=1000, emit=None):
         if emit is not None:
             emit(lines[-1])
 
-    models = ["simple", "simple_string", "repeat_int32"]
+    models = ["simple", "simple_string", "repeat_int32", "simple_sequence"]
     with spawn_server(models=models, gpu=gpu) as srv:
         common = ["-p", str(window_ms), "--stability-windows", "2", "--warmup-ms", "300"]
         rows = perf(["-m", "simple", "-u", srv.http_url, "-i", "http", "--shared-memory", "system", "--native",
@@ -48,6 +50,10 @@ def run_configs(gpu=None, window_ms=1000, emit=None):
                      "--shape", "DELAY:16", "--shape", "WAIT:1", "--concurrency-range", "16"] + common)
         add("decoupled_stream", concurrency=16, responses_per_request=16, requests_per_sec=rows[0]["requests_per_sec"],
             responses_per_sec=rows[0]["responses_per_sec"], p50_us=rows[0]["p50_us"], p99_us=rows[0]["p99_us"])
+        rows = perf(["-m", "simple_sequence", "-u", srv.grpc_url, "-i", "grpc", "--native", "--streaming",
+                     "--sequence-length", "20", "--concurrency-range", "16"] + common)
+        add("sequence_stream", concurrency=16, sequence_length=20, infer_per_sec=rows[0]["infer_per_sec"],
+            p50_us=rows[0]["p50_us"], p99_us=rows[0]["p99_us"])
     return lines
 
 

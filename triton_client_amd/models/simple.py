@@ -298,6 +298,7 @@ class SimpleSequence(_SequenceBase):
     """``OUTPUT = INPUT`` (+1 on the first request of a sequence)."""
 
     name = "simple_sequence"
+    native_kernel = "sequence"  # numeric correlation ids: answered in C++, which also keeps the table of open sequences
 
     def execute(self, inputs, ctx):
         value = inputs["INPUT"].astype(np.int32)
@@ -318,6 +319,7 @@ class SimpleDynaSequence(_SequenceBase):
     """Like ``simple_sequence`` and adds the correlation id on sequence end."""
 
     name = "simple_dyna_sequence"
+    native_kernel = "dyna_sequence"
 
     def execute(self, inputs, ctx):
         value = inputs["INPUT"].astype(np.int32)

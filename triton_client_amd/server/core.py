@@ -699,9 +699,11 @@ class InferenceCore:
             return
         model = lm.model
         kernel = getattr(model, "native_kernel", None)
+        stateful = kernel in ("sequence", "dyna_sequence")
         eligible = present and kernel and model.device == "cpu" and not model.parameters \
-            and not getattr(model, "sequence", False) and (not model.decoupled or kernel == "repeat") \
+            and bool(getattr(model, "sequence", False)) == stateful and (not model.decoupled or kernel == "repeat") \
             and (not kernel.startswith("bytes_") or self.devshm.native is not None)
+        lm.native_sequences = False
         if not eligible:
             executor.remove_model(model.name)
             return
@@ -709,6 +711,9 @@ class InferenceCore:
             executor.set_model(model.name, model.versions[-1], int(model.max_batch_size),
                                [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.inputs],
                                [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.outputs], kernel)
+            # the table of open sequences (numeric correlation ids) lives in the executor from here on:
+            # requests answered there and requests that come through infer() see the same one
+            lm.native_sequences = bool(stateful)
         except ValueError:
             executor.remove_model(model.name)
 
@@ -1056,6 +1061,12 @@ class InferenceCore:
                 f"inference request to model '{lm.model.name}' must specify a non-zero or non-empty correlation ID")
         start = bool(params.get("sequence_start", False))
         end = bool(params.get("sequence_end", False))
+        if getattr(lm, "native_sequences", False) and type(seq_id) is int and 0 < seq_id < (1 << 63):
+            if not self.native.sequence_step(lm.model.name, seq_id, start, end):
+                raise ServerError(
+                    f"inference request for sequence {seq_id} to model '{lm.model.name}' must specify the START "
+                    "flag on the first request of the sequence")
+            return SequenceInfo(sequence_id=seq_id, start=start, end=end, state={})
         with lm.seq_lock:
             state = lm.sequences.get(seq_id)
             if start or state is None:
