@@ -52,11 +52,12 @@ def test_documented_models_headers_tools_and_switches_exist():
     server = _read("server.md")
     table = server.split("## Models")[1].split("A model is a subclass")[0]
     for name in re.findall(r"`([a-z0-9_]+)`", table):
-        if name in ("execute_delay_ms", "identity", "repeat", "bytes_add_sub", "bytes_identity"):
+        if name in ("execute_delay_ms", "identity", "repeat", "bytes_add_sub", "bytes_identity", "sequence",
+                    "dyna_sequence"):
             continue  # a parameter and the native kernels the notes column names
         assert name in MODEL_ZOO, name
     kernels = re.findall(r'spec\.kernel == "([a-z_]+)"', open(os.path.join(ROOT, "csrc/server/native_executor.cc")).read())
-    for name in ("identity", "repeat", "bytes_add_sub", "bytes_identity", "add_sub"):
+    for name in ("identity", "repeat", "bytes_add_sub", "bytes_identity", "add_sub", "sequence", "dyna_sequence"):
         assert name in kernels, name
     cpp = _read("cpp_client.md")
     for header in set(re.findall(r"`(tca/[a-z0-9_]+\.h)`", cpp)):
