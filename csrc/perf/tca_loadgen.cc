@@ -9,7 +9,8 @@
 //       --warmup-count W     (with --count) W unmeasured requests first
 //       --wait-go            (with --count) print READY after the warm-up and start the
 //                            measured phase when a line arrives on stdin
-//       --connections M      gRPC: spread the slots over M channels (default 1)
+//       --connections M      spread the slots over M clients (gRPC: channels; HTTP: clients with a
+//                            reactor thread and a connection pool each) (default 1)
 //       --trace FILE         write one CSV row per measured request:
 //                            start_ns (since the measured phase began), latency_ns, slot, ok
 //       --shape NAME:DATATYPE:d0,d1,...      wire tensors (zero filled)
@@ -115,7 +116,7 @@ int main(int argc, char** argv) {
   const bool use_grpc = protocol == "grpc";
   if (!use_grpc && protocol != "http") { std::cerr << "-i must be http or grpc" << std::endl; return 2; }
   if (streaming && !use_grpc) { std::cerr << "--streaming needs -i grpc" << std::endl; return 2; }
-  std::unique_ptr<tc::InferenceServerHttpClient> client;
+  std::vector<std::unique_ptr<tc::InferenceServerHttpClient>> http_clients;
   std::vector<std::unique_ptr<tc::InferenceServerGrpcClient>> grpc_clients;
   tca::Error e;
   if (use_grpc) {
@@ -127,8 +128,12 @@ int main(int argc, char** argv) {
       grpc_clients.push_back(std::move(g));
     }
   } else {
-    e = tc::InferenceServerHttpClient::Create(&client, url);
-    if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+    for (int k = 0; k < connections; ++k) {
+      std::unique_ptr<tc::InferenceServerHttpClient> h;
+      e = tc::InferenceServerHttpClient::Create(&h, url);
+      if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
+      http_clients.push_back(std::move(h));
+    }
   }
 
   // one request template per slot; `{slot}` in region names is replaced by the slot index
@@ -296,7 +301,7 @@ int main(int argc, char** argv) {
         complete(s, status, t1);
       };
       se = use_grpc ? grpc_clients[s % grpc_clients.size()]->AsyncInfer(on_done, per_request, slot->in_ptrs, slot->out_ptrs)
-                    : client->AsyncInfer(on_done, per_request, slot->in_ptrs, slot->out_ptrs);
+                    : http_clients[s % http_clients.size()]->AsyncInfer(on_done, per_request, slot->in_ptrs, slot->out_ptrs);
     }
     if (!se.IsOk()) {
       std::lock_guard<std::mutex> lk(mu);
