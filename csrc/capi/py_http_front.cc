@@ -61,8 +61,10 @@ bool InferTarget(const std::string& target, std::string* model, std::string* ver
   return !model->empty() && !version->empty() && version->find('/') == std::string::npos;
 }
 
-// True when the native path answered the request.
-bool TryNative(PyHttpFront* self, uint64_t call, const tca::server::HttpServerFront::Request& req) {
+void DeliverRequest(PyHttpFront* self, uint64_t call, tca::server::HttpServerFront::Request& req);
+
+// True when the native path answered the request, or has queued it and will answer (or hand it on) later.
+bool TryNative(PyHttpFront* self, uint64_t call, tca::server::HttpServerFront::Request& req) {
   if (self->native == nullptr || req.method != "POST") return false;
   std::string model, version;
   if (!InferTarget(req.target, &model, &version)) return false;
@@ -78,7 +80,39 @@ bool TryNative(PyHttpFront* self, uint64_t call, const tca::server::HttpServerFr
   }
   tca::server::HttpServerFront::HeaderList headers;
   std::vector<std::string> parts;
-  if (!(*self->native)->TryHttp(model, version, req.body, header_length, &headers, &parts)) return false;
+  if (!(*self->native)->Defers(model)) {  // answered on this reactor thread, or not at all
+    if (!(*self->native)->TryHttp(model, version, req.body, header_length, &headers, &parts)) return false;
+    self->front->Respond(call, 200, std::move(headers), std::move(parts));
+    return true;
+  }
+  using Outcome = tca::server::NativeExecutor::Outcome;
+  // a model whose requests are queued for the device: the completion keeps what the general path needs besides
+  // the body, should the device refuse the request
+  const Outcome outcome = (*self->native)->TryHttpAsync(
+      model, version, &req.body, header_length, &headers, &parts,
+      [self, call, method = req.method, target = req.target, request_headers = req.headers](
+          bool ok, tca::server::HttpServerFront::HeaderList&& h, std::vector<std::string>&& p) mutable {
+        if (ok) {  // answered by the executor's batch thread
+          self->front->Respond(call, 200, std::move(h), std::move(p));
+          return;
+        }
+        // the device refused it: the general path takes the request and words the error
+        auto shared = std::make_shared<tca::server::HttpServerFront::Request>();
+        shared->method = std::move(method);
+        shared->target = std::move(target);
+        shared->headers = std::move(request_headers);
+        if (!p.empty()) shared->body = std::move(p[0]);
+        auto deliver = [self, call, shared] { DeliverRequest(self, call, *shared); };
+        if (self->funnel != nullptr) {
+          self->funnel->Run(deliver);
+          return;
+        }
+        PyGILState_STATE gil = PyGILState_Ensure();
+        deliver();
+        PyGILState_Release(gil);
+      });
+  if (outcome == Outcome::kDeferred) return true;
+  if (outcome != Outcome::kAnswered) return false;
   self->front->Respond(call, 200, std::move(headers), std::move(parts));
   return true;
 }
@@ -184,8 +218,10 @@ void StopFront(PyHttpFront* self) {
   tca::server::HttpServerFront* front = self->front;
   tca::capi::GilFunnel* funnel = self->funnel;
   // reactor / funnel threads may be waiting for the GIL inside a callback: let them finish
+  tca::server::NativeExecutor* native = self->native != nullptr ? self->native->get() : nullptr;
   Py_BEGIN_ALLOW_THREADS
   front->Stop();
+  if (native != nullptr) native->Quiesce();  // queued requests answer through this front (and may need the funnel)
   if (funnel != nullptr) funnel->Stop();
   Py_END_ALLOW_THREADS
 }

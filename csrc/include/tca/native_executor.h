@@ -81,6 +81,9 @@ class NativeExecutor {
   // ok: `payload` is the serialized response.  Not ok: the device refused the request (malformed stream,
   // output range too small...): `payload` is the request, which the caller hands to the general path.
   using Completion = std::function<void(bool ok, std::string&& payload)>;
+  using HeaderList = std::vector<std::pair<std::string, std::string>>;
+  // The HTTP form: ok: response headers and parts.  Not ok: `parts` holds the request body alone.
+  using HttpCompletion = std::function<void(bool ok, HeaderList&& headers, std::vector<std::string>&& parts)>;
   struct BatchStats {
     uint64_t count = 0, input_ns = 0, infer_ns = 0, output_ns = 0;
   };
@@ -88,7 +91,6 @@ class NativeExecutor {
     uint64_t requests = 0, inferences = 0, queue_ns = 0, last_ms = 0;
     std::map<int, BatchStats> by_batch;
   };
-  using HeaderList = std::vector<std::pair<std::string, std::string>>;
 
   Error SetModel(const ModelSpec& spec);
   void RemoveModel(const std::string& name);
@@ -133,6 +135,13 @@ class NativeExecutor {
   // Sequences of `name` that have been started and not ended (-1: no such model).
   long OpenSequences(const std::string& name);
 
+  // Whether requests for `model` may be deferred (a device BYTES kernel): only those need TryGrpcAsync / TryHttpAsync.
+  bool Defers(const std::string& model);
+  // TryHttp plus the device BYTES path.  kDeferred: `*body` has been moved into the queue and `done` runs later
+  // on the batch thread.
+  Outcome TryHttpAsync(const std::string& model, const std::string& version, std::string* body, int64_t header_length,
+                       HeaderList* headers, std::vector<std::string>* parts, HttpCompletion done);
+
   // Moves the statistics accumulated for `name` since the last call into `out`; false if there are none.
   bool TakeStats(const std::string& name, Stats* out);
   uint64_t Handled() const { return handled_.load(); }
@@ -172,6 +181,10 @@ class NativeExecutor {
   bool Run(Request* req, const std::shared_ptr<Model>& model);
   bool RunRepeat(Request* req, const std::shared_ptr<Model>& model, std::vector<std::string>* responses);
   bool ParseGrpc(const std::string& request, bool stream, Request* out, std::shared_ptr<Model>* model);
+  bool ParseHttp(const std::string& model_name, const std::string& version, const std::string& body, int64_t header_length,
+                 Request* out, std::shared_ptr<Model>* model);
+  static void BuildHttpResponse(const Request& req, std::vector<Result>* results, HeaderList* headers,
+                                std::vector<std::string>* parts);
   std::shared_ptr<Model> FindModel(const std::string& name, const std::string& version);
 
   std::atomic<bool> enabled_{true};

@@ -109,7 +109,8 @@ struct NativeExecutor::DeviceJob {
   Request req;  // results already describe the answer; the kernels fill the regions
   std::shared_ptr<Model> model;
   std::string request_bytes;  // handed back when the device refuses the request
-  Completion done;
+  Completion done;            // gRPC caller ...
+  HttpCompletion http_done;   // ... or HTTP caller (exactly one of the two is set)
   int op = 0;
   uint32_t count = 0;
   int batch = 1;
@@ -966,8 +967,11 @@ bool NativeExecutor::PrepareDeviceJob(Request* req, const std::shared_ptr<Model>
 
 void NativeExecutor::FinishDeviceJob(DeviceJob* job, bool ok) {
   std::string payload;
+  HeaderList headers;
+  std::vector<std::string> parts;
   if (ok) {
-    BuildGrpcResponse(job->req, job->req.results, -1, &payload);
+    if (job->http_done) BuildHttpResponse(job->req, &job->req.results, &headers, &parts);
+    else BuildGrpcResponse(job->req, job->req.results, -1, &payload);
     const uint64_t now = NowNs();
     std::lock_guard<std::mutex> lk(job->model->stats_mu);
     Stats& s = job->model->stats;
@@ -988,7 +992,12 @@ void NativeExecutor::FinishDeviceJob(DeviceJob* job, bool ok) {
   // the regions are free again before the caller hears about it: it may unregister them right away
   for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
   job->leases.clear();
-  job->done(ok, std::move(payload));
+  if (job->http_done) {
+    if (!ok) parts.assign(1, std::move(payload));  // the request body, for the general path
+    job->http_done(ok, std::move(headers), std::move(parts));
+  } else {
+    job->done(ok, std::move(payload));
+  }
 }
 
 void NativeExecutor::DeviceLoop() {
@@ -1044,16 +1053,18 @@ void NativeExecutor::DeviceLoop() {
 
 NativeExecutor::Outcome NativeExecutor::TryGrpcAsync(std::string* request, std::string* response, Completion done) {
   if (!enabled_.load(std::memory_order_relaxed)) return Outcome::kDeclined;
-  auto job = std::make_unique<DeviceJob>();
+  Request req;
   std::shared_ptr<Model> model;
-  if (!ParseGrpc(*request, false, &job->req, &model)) return Outcome::kDeclined;
+  if (!ParseGrpc(*request, false, &req, &model)) return Outcome::kDeclined;
   if (model->kernel == kRepeat) return Outcome::kDeclined;
   if (model->kernel == kBytesAddSub || model->kernel == kBytesIdentity) {
-    if (!pipe_on_.load(std::memory_order_acquire) || !PrepareDeviceJob(&job->req, model, job.get())) {
+    auto job = std::make_unique<DeviceJob>();
+    if (!pipe_on_.load(std::memory_order_acquire) || !PrepareDeviceJob(&req, model, job.get())) {
       declined_.fetch_add(1, std::memory_order_relaxed);
       return Outcome::kDeclined;
     }
-    job->req.inputs.clear();  // pointed into the request bytes, which move now
+    req.inputs.clear();  // pointed into the request bytes, which move now
+    job->req = std::move(req);
     job->model = std::move(model);
     job->request_bytes = std::move(*request);
     job->done = std::move(done);
@@ -1069,7 +1080,6 @@ NativeExecutor::Outcome NativeExecutor::TryGrpcAsync(std::string* request, std::
     q_cv_.notify_one();
     return Outcome::kDeferred;
   }
-  Request& req = job->req;
   if (!Run(&req, model)) {
     declined_.fetch_add(1, std::memory_order_relaxed);
     return Outcome::kDeclined;
@@ -1122,12 +1132,12 @@ bool HttpParams(const json::Value* params, ShmRef* shm, int64_t* binary_size, bo
 
 }  // namespace
 
-bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& version, const std::string& body,
-                             int64_t header_length, HeaderList* headers, std::vector<std::string>* parts) {
-  if (!enabled_.load(std::memory_order_relaxed)) return false;
+// Decodes the JSON header (+ binary tensors) of an HTTP inference request.
+bool NativeExecutor::ParseHttp(const std::string& model_name, const std::string& version, const std::string& body,
+                               int64_t header_length, Request* out, std::shared_ptr<Model>* model_out) {
   std::shared_ptr<Model> model = FindModel(model_name, version);
   if (!model) return false;
-  Request req;
+  Request& req = *out;
   req.t_arrive = NowNs();
   req.model = model_name;
   req.version = version;
@@ -1222,11 +1232,13 @@ bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& v
   } else if (!default_binary) {
     return false;
   }
-  if (!Run(&req, model)) {
-    declined_.fetch_add(1, std::memory_order_relaxed);
-    return false;
-  }
-  const uint64_t t2 = NowNs();
+  *model_out = std::move(model);
+  return true;
+}
+
+// JSON header (+ one part per output that is not in shared memory) of the results.
+void NativeExecutor::BuildHttpResponse(const Request& req, std::vector<Result>* results, HeaderList* headers,
+                                       std::vector<std::string>* parts) {
   std::string head;
   head.reserve(384);
   head += "{\"model_name\":";
@@ -1239,7 +1251,7 @@ bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& v
   }
   head += ",\"outputs\":[";
   bool first = true, any_blob = false;
-  for (const auto& res : req.results) {
+  for (const auto& res : (*results)) {
     if (!first) head += ',';
     first = false;
     head += "{\"name\":";
@@ -1269,8 +1281,22 @@ bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& v
     headers->emplace_back("Content-Type", "application/octet-stream");
   }
   parts->push_back(std::move(head));
-  for (auto& res : req.results)
+  for (auto& res : (*results))
     if (!res.shm.set) parts->push_back(std::move(res.bytes));
+}
+
+bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& version, const std::string& body,
+                             int64_t header_length, HeaderList* headers, std::vector<std::string>* parts) {
+  if (!enabled_.load(std::memory_order_relaxed)) return false;
+  Request req;
+  std::shared_ptr<Model> model;
+  if (!ParseHttp(model_name, version, body, header_length, &req, &model)) return false;
+  if (!Run(&req, model)) {
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return false;
+  }
+  const uint64_t t2 = NowNs();
+  BuildHttpResponse(req, &req.results, headers, parts);
   {
     int batch = 1;
     if (model->spec.max_batch > 0 && !req.results.empty() && !req.results[0].shape.empty())
@@ -1280,6 +1306,59 @@ bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& v
   }
   handled_.fetch_add(1, std::memory_order_relaxed);
   return true;
+}
+
+
+bool NativeExecutor::Defers(const std::string& model) {
+  std::shared_ptr<Model> m = FindModel(model, std::string());
+  return m && (m->kernel == kBytesAddSub || m->kernel == kBytesIdentity) && pipe_on_.load(std::memory_order_acquire);
+}
+
+NativeExecutor::Outcome NativeExecutor::TryHttpAsync(const std::string& model_name, const std::string& version,
+                                                     std::string* body, int64_t header_length, HeaderList* headers,
+                                                     std::vector<std::string>* parts, HttpCompletion done) {
+  if (!enabled_.load(std::memory_order_relaxed)) return Outcome::kDeclined;
+  Request req;
+  std::shared_ptr<Model> model;
+  if (!ParseHttp(model_name, version, *body, header_length, &req, &model)) return Outcome::kDeclined;
+  if (model->kernel == kBytesAddSub || model->kernel == kBytesIdentity) {
+    auto job = std::make_unique<DeviceJob>();
+    if (!pipe_on_.load(std::memory_order_acquire) || !PrepareDeviceJob(&req, model, job.get())) {
+      declined_.fetch_add(1, std::memory_order_relaxed);
+      return Outcome::kDeclined;
+    }
+    req.inputs.clear();  // pointed into the body, which moves now
+    job->req = std::move(req);
+    job->model = std::move(model);
+    job->request_bytes = std::move(*body);
+    job->http_done = std::move(done);
+    {
+      std::lock_guard<std::mutex> lk(q_mu_);
+      if (stop_) {
+        *body = std::move(job->request_bytes);
+        for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
+        return Outcome::kDeclined;
+      }
+      queue_.push_back(std::move(job));
+    }
+    q_cv_.notify_one();
+    return Outcome::kDeferred;
+  }
+  if (!Run(&req, model)) {
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return Outcome::kDeclined;
+  }
+  const uint64_t t2 = NowNs();
+  BuildHttpResponse(req, &req.results, headers, parts);
+  {
+    int batch = 1;
+    if (model->spec.max_batch > 0 && !req.results.empty() && !req.results[0].shape.empty())
+      batch = static_cast<int>(req.results[0].shape[0]);
+    std::lock_guard<std::mutex> lk(model->stats_mu);
+    model->stats.by_batch[batch].output_ns += NowNs() - t2;
+  }
+  handled_.fetch_add(1, std::memory_order_relaxed);
+  return Outcome::kAnswered;
 }
 
 }  // namespace server

@@ -365,6 +365,59 @@ void DeviceBytesPath() {
   NativeExecutor::Stats st;
   if (!ex.TakeStats("simple_string", &st) || st.requests != static_cast<uint64_t>(answered.load()))
     Fail("device bytes: statistics do not match the answered requests");
+  {
+    // the HTTP form of the same request: answered with a JSON header that echoes the output regions, or handed back
+    auto http_body = [&](int64_t in_size, int64_t out_cap) {
+      std::string b = "{\"id\":\"h1\",\"inputs\":[";
+      for (int k = 0; k < 2; ++k) {
+        if (k) b += ",";
+        b += "{\"name\":\"INPUT" + std::to_string(k) + "\",\"datatype\":\"BYTES\",\"shape\":[1,16],\"parameters\":{"
+             "\"shared_memory_region\":\"dev\",\"shared_memory_byte_size\":" + std::to_string(in_size) +
+             ",\"shared_memory_offset\":" + std::to_string(256 * k) + "}}";
+      }
+      b += "],\"outputs\":[";
+      for (int k = 0; k < 2; ++k) {
+        if (k) b += ",";
+        b += "{\"name\":\"OUTPUT" + std::to_string(k) + "\",\"parameters\":{\"shared_memory_region\":\"dev\","
+             "\"shared_memory_byte_size\":" + std::to_string(out_cap) + ",\"shared_memory_offset\":" +
+             std::to_string(512 + 256 * k) + "}}";
+      }
+      return b + "]}";
+    };
+    std::vector<std::string> items;
+    for (int e = 0; e < 16; ++e) items.push_back(std::to_string(e + 1));
+    uint64_t size = 0;
+    PackStream(items, memory.data(), 256, &size);
+    PackStream(items, memory.data() + 256, 256, &size);
+    if (!ex.Defers("simple_string")) Fail("device bytes: the model is not reported as deferring");
+    for (const bool small : {false, true}) {
+      std::string body = http_body(static_cast<int64_t>(size), small ? 8 : 256);
+      const std::string copy = body;
+      NativeExecutor::HeaderList headers;
+      std::vector<std::string> parts, got;
+      std::atomic<int> verdict{-1};
+      if (ex.TryHttpAsync("simple_string", "", &body, -1, &headers, &parts,
+                          [&](bool ok, NativeExecutor::HeaderList&&, std::vector<std::string>&& p) {
+                            got = std::move(p);
+                            verdict.store(ok ? 1 : 0);
+                          }) != NativeExecutor::Outcome::kDeferred)
+        Fail("device bytes: the HTTP request was not queued");
+      ex.Quiesce();
+      if (small) {
+        if (verdict.load() != 0 || got.size() != 1 || got[0] != copy) Fail("device bytes: HTTP refusal without the body");
+      } else if (verdict.load() != 1 || got.size() != 1 || got[0].find("\"shared_memory_region\":\"dev\"") == std::string::npos ||
+                 got[0].find("\"id\":\"h1\"") == std::string::npos) {
+        Fail("device bytes: HTTP answer");
+      } else {
+        std::vector<std::string> doubled;
+        for (int e = 0; e < 16; ++e) doubled.push_back(std::to_string(2 * (e + 1)));
+        std::vector<uint8_t> expect(256);
+        uint64_t want = 0;
+        PackStream(doubled, expect.data(), 256, &want);
+        if (std::memcmp(memory.data() + 512, expect.data(), want) != 0) Fail("device bytes: HTTP result");
+      }
+    }
+  }
   std::string unnamed = StringRequest("dev", 40, 0, 256, false);
   if (ex.TryGrpcAsync(&unnamed, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
     Fail("device bytes: outputs without regions must take the general path");

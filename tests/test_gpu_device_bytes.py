@@ -90,6 +90,41 @@ def test_string_add_sub_golden_bytes(served, batch):
             _cleanup(hipshm, c, handles)
 
 
+def test_http_requests_take_the_same_path(served):
+    """The REST front: tensors in device regions, the same kernels, the same bytes; the response names the
+    output regions.  A result that does not fit is refused in the general path's words."""
+    import tritonclient.http as h
+    import tritonclient.utils.cuda_shared_memory as hipshm
+    from tritonclient.utils import InferenceServerException, serialize_byte_tensor
+
+    a = np.arange(-8, 8).reshape(1, 16) * 1234567
+    b = np.arange(16).reshape(1, 16) - 5
+    sa = np.array([str(v).encode() for v in a.reshape(-1)], dtype=object).reshape(1, 16)
+    sb = np.array([str(v).encode() for v in b.reshape(-1)], dtype=object).reshape(1, 16)
+    blob_a, blob_b = serialize_byte_tensor(sa).item(), serialize_byte_tensor(sb).item()
+    with h.InferenceServerClient(served.http_url) as c:
+        handles = _regions(hipshm, c, ["ht_in0", "ht_in1", "ht_out0", "ht_out1"], 2048)
+        try:
+            hipshm.set_shared_memory_region(handles["ht_in0"], [serialize_byte_tensor(sa)])
+            hipshm.set_shared_memory_region(handles["ht_in1"], [serialize_byte_tensor(sb)])
+            ins, outs = _request(h, 1, "ht", [len(blob_a), len(blob_b)], 2048)
+            res = c.infer("simple_string", ins, outputs=outs, request_id="rest-1")
+            body = res.get_response()
+            assert body["id"] == "rest-1" and body["model_name"] == "simple_string"
+            out0 = res.get_output("OUTPUT0")
+            assert out0["shape"] == [1, 16] and out0["parameters"]["shared_memory_region"] == "ht_out0"
+            for name, expect in (("out0", a + b), ("out1", a - b)):
+                want = serialize_byte_tensor(np.array([str(v).encode() for v in expect.reshape(-1)],
+                                                      dtype=object)).item()
+                raw = hipshm.get_contents_as_numpy(handles[f"ht_{name}"], np.uint8, [len(want)])
+                assert raw.tobytes() == want
+            ins, outs = _request(h, 1, "ht", [len(blob_a), len(blob_b)], 16)
+            with pytest.raises(InferenceServerException, match="too small|should be at least"):
+                c.infer("simple_string", ins, outputs=outs)
+        finally:
+            _cleanup(hipshm, c, handles)
+
+
 def test_client_reads_only_the_stream(served):
     """The device path leaves an index behind the result; the client fetches the index and then
     exactly the stream - not the rest of a large region."""
