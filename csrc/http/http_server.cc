@@ -183,6 +183,16 @@ struct HttpServerFront::Reactor {
   }
 
   // Consumes what it can from c->rbuf.
+  static constexpr size_t kBodyFirstAllocation = size_t(4) << 20;
+  // Makes room for `need` more body bytes behind the ones received (never past the declared length): the
+  // buffer doubles, so a body of n bytes is copied at most once more in total while it grows.
+  static void GrowBody(Conn* c, size_t need) {
+    std::string& body = c->req.body;
+    if (body.size() - c->body_filled >= need) return;
+    const size_t total = c->body_filled + c->body_left;
+    body.resize(std::min(total, std::max(body.size() * 2, c->body_filled + need)));
+  }
+
   void Parse(Conn* c) {
     for (;;) {
       switch (c->phase) {
@@ -206,6 +216,7 @@ struct HttpServerFront::Reactor {
           // the body was sized from Content-Length when the head was parsed
           const size_t take = std::min(c->body_left, c->rbuf.size());
           if (take) {
+            GrowBody(c, take);
             std::memcpy(&c->req.body[c->body_filled], c->rbuf.data(), take);
             c->rbuf.erase(0, take);
             c->body_filled += take;
@@ -326,7 +337,9 @@ struct HttpServerFront::Reactor {
       }
       c->body_left = static_cast<size_t>(length);
       c->body_filled = 0;
-      r.body.resize(c->body_left);  // received in place: from the head's tail by memcpy, then straight from the socket
+      // received in place: from the head's tail by memcpy, then straight from the socket.  Bodies up to 4 MiB are
+      // sized once; larger ones grow as their bytes arrive (GrowBody), so a peer that only CLAIMS gigabytes costs nothing.
+      r.body.resize(std::min(c->body_left, kBodyFirstAllocation));
       c->phase = Phase::BODY;
     } else {
       c->phase = Phase::BODY;
@@ -458,7 +471,8 @@ struct HttpServerFront::Reactor {
         }
       } else if (c->phase == Phase::BODY && c->rbuf.empty() && c->body_left >= 65536) {
         // a large body: receive straight into the request's buffer, no bounce through `buf`
-        n = recv(c->fd, &c->req.body[c->body_filled], c->body_left, 0);
+        GrowBody(c, 1);
+        n = recv(c->fd, &c->req.body[c->body_filled], std::min(c->body_left, c->req.body.size() - c->body_filled), 0);
         if (n > 0) {
           c->body_filled += static_cast<size_t>(n);
           c->body_left -= static_cast<size_t>(n);

@@ -9,8 +9,17 @@
 // with the in-tree gRPC client: synchronous and asynchronous inference (add / subtract on
 // INT32[1,16], checked), control calls through a shared client, bidirectional streams with
 // several responses per request, deadlines that expire while the backend still holds the
-// call, and clients that go away with calls in flight.  The reference has no server and
+// call, and clients that go away with calls in flight.  A hostile peer runs beside them: raw
+// connections that send random bytes, and valid HTTP/2 prefaces followed by frames with random
+// types, flags, lengths, stream ids and payloads (HPACK blocks included) - the front may answer
+// with GOAWAY or close, it may not crash, leak or stop serving the others.  The reference has no server and
 // configures no sanitizers; this is the serving-side counterpart of stress_test.cc.
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -385,6 +394,54 @@ void ClientThread(int t, int rounds, const std::string& url, tc::InferenceServer
   }
 }
 
+// One hostile connection: `preface` decides whether the bytes start like HTTP/2.
+void HostileConnection(int port, std::mt19937_64* rng, bool preface) {
+  const int fd = socket(AF_INET, SOCK_STREAM, 0);
+  if (fd < 0) return;
+  sockaddr_in addr{};
+  addr.sin_family = AF_INET;
+  addr.sin_port = htons(static_cast<uint16_t>(port));
+  addr.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+  timeval tv{0, 200000};
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+  setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+  if (connect(fd, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)) != 0) {
+    close(fd);
+    return;
+  }
+  std::string out;
+  if (preface) {
+    out = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";
+    out.append("\0\0\0\4\0\0\0\0\0", 9);  // empty SETTINGS
+    const int frames = 1 + static_cast<int>((*rng)() % 12);
+    for (int f = 0; f < frames; ++f) {
+      const uint32_t declared = (*rng)() % 5 == 0 ? static_cast<uint32_t>((*rng)() % (1u << 24)) : static_cast<uint32_t>((*rng)() % 64);
+      const uint32_t actual = std::min<uint32_t>(declared, static_cast<uint32_t>((*rng)() % 96));
+      const uint8_t type = static_cast<uint8_t>((*rng)() % 12);
+      const uint8_t flags = static_cast<uint8_t>((*rng)());
+      const uint32_t stream = (*rng)() % 4 == 0 ? static_cast<uint32_t>((*rng)()) : static_cast<uint32_t>((*rng)() % 8);
+      const char head[9] = {static_cast<char>(declared >> 16), static_cast<char>(declared >> 8), static_cast<char>(declared),
+                            static_cast<char>(type), static_cast<char>(flags), static_cast<char>(stream >> 24),
+                            static_cast<char>(stream >> 16), static_cast<char>(stream >> 8), static_cast<char>(stream)};
+      out.append(head, 9);
+      for (uint32_t k = 0; k < actual; ++k) out.push_back(static_cast<char>((*rng)()));
+    }
+  } else {
+    const int n = 1 + static_cast<int>((*rng)() % 600);
+    for (int k = 0; k < n; ++k) out.push_back(static_cast<char>((*rng)()));
+  }
+  (void)!send(fd, out.data(), out.size(), MSG_NOSIGNAL);
+  char buf[4096];
+  for (int k = 0; k < 3 && recv(fd, buf, sizeof(buf), 0) > 0; ++k) {
+  }
+  close(fd);
+}
+
+void HostilePeer(int port, int connections, uint64_t seed) {
+  std::mt19937_64 rng(seed);
+  for (int c = 0; c < connections; ++c) HostileConnection(port, &rng, c % 4 != 0);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -428,7 +485,11 @@ int main(int argc, char** argv) {
     }
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; ++t) pool.emplace_back(ClientThread, t, rounds, url, shared.get());
+    pool.emplace_back(HostilePeer, front.port(), 40 * rounds, 12345);
     for (auto& th : pool) th.join();
+    // the front still serves after all that
+    bool live = false;
+    if (!shared->IsServerLive(&live).IsOk()) Fail("the front stopped answering after the hostile connections");
   }
   // late stream closers and held calls drain before the front goes away
   std::this_thread::sleep_for(std::chrono::milliseconds(300));

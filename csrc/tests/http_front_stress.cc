@@ -15,6 +15,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -265,6 +266,41 @@ size_t Count(const std::string& hay, const std::string& needle) {
   return n;
 }
 
+// A hostile peer: well-formed requests (Content-Length, chunked, pipelined, Expect) with a few bytes flipped,
+// overwritten, inserted or removed, and plain random bytes.  Any answer or a closed connection is fine; a crash,
+// a leak or an access outside a buffer is what the detectors are watching for.
+void HostilePeer(int port, int connections, uint64_t seed) {
+  std::mt19937_64 rng(seed);
+  const std::string json = "{\"inputs\":[{\"name\":\"INPUT0\",\"datatype\":\"INT32\",\"shape\":[1,16],\"data\":[1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16]},"
+                           "{\"name\":\"INPUT1\",\"datatype\":\"INT32\",\"shape\":[1,16],\"data\":[1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1]}]}";
+  const std::string seeds[4] = {
+      "POST /v2/models/simple/infer HTTP/1.1\r\nHost: x\r\nContent-Length: " + std::to_string(json.size()) + "\r\n\r\n" + json,
+      "POST /v2/models/simple/infer HTTP/1.1\r\nHost: x\r\nTransfer-Encoding: chunked\r\n\r\n20\r\n" + json.substr(0, 32) + "\r\n" +
+          "a\r\n" + json.substr(32, 10) + "\r\n0\r\n\r\n",
+      "GET /v2/health/live HTTP/1.1\r\nHost: x\r\n\r\nGET /v2/models/simple HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n",
+      "POST /v2/models/simple/infer HTTP/1.1\r\nHost: x\r\nExpect: 100-continue\r\nInference-Header-Content-Length: 40\r\nContent-Length: 99999999\r\n\r\n" + json};
+  for (int c = 0; c < connections; ++c) {
+    std::string m;
+    if (c % 5 == 4) {
+      const int n = 1 + static_cast<int>(rng() % 500);
+      for (int k = 0; k < n; ++k) m.push_back(static_cast<char>(rng()));
+    } else {
+      m = seeds[rng() % 4];
+      const int edits = 1 + static_cast<int>(rng() % 4);
+      for (int k = 0; k < edits && !m.empty(); ++k) {
+        const size_t at = rng() % std::min<size_t>(m.size(), 160);  // mostly the head: that is where the parser works
+        switch (rng() % 4) {
+          case 0: m[at] = static_cast<char>(m[at] ^ (1 << (rng() % 8))); break;
+          case 1: m[at] = static_cast<char>(rng()); break;
+          case 2: m.insert(at, 1, static_cast<char>(rng())); break;
+          default: m.erase(at, 1 + rng() % 3); break;
+        }
+      }
+    }
+    Raw(port, m, /*drop_early=*/c % 3 == 0);
+  }
+}
+
 // The HTTP client is a one-thread object (like the reference's): the shared one is used under a lock.
 std::mutex g_shared_mu;
 
@@ -383,7 +419,10 @@ int main(int argc, char** argv) {
     }
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; ++t) pool.emplace_back(ClientThread, t, rounds, url, front.port(), shared.get());
+    pool.emplace_back(HostilePeer, front.port(), 30 * rounds, 4242);
     for (auto& t : pool) t.join();
+    bool live = false;
+    if (!shared->IsServerLive(&live).IsOk() || !live) Fail("the front stopped answering after the hostile connections");
   }
   std::this_thread::sleep_for(std::chrono::milliseconds(100));  // answers of abandoned requests drain
   backend.Stop();

@@ -656,6 +656,46 @@ int main() {
   }
   NativeExecutor::HeaderList headers;
   std::vector<std::string> parts;
+  {
+    // mutated requests (the parsers read bytes from the network): flipped bits, overwritten and inserted bytes.
+    // Whatever comes out - an answer or a refusal - no access may leave the message (the memory-error
+    // detectors watch this loop).
+    uint64_t rng = 0x9e3779b97f4a7c15ull;
+    auto next = [&rng]() {
+      rng ^= rng << 13;
+      rng ^= rng >> 7;
+      rng ^= rng << 17;
+      return rng;
+    };
+    const std::string seeds[3] = {GrpcRequest(a, b, 1, false), GrpcRequest(a, b, 1, true),
+                                  SequenceRequest("simple", 3, 9, true, false)};
+    const std::string http_seed =
+        "{\"id\":\"7\",\"inputs\":[{\"name\":\"INPUT0\",\"datatype\":\"INT32\",\"shape\":[1,16],\"parameters\":{\"binary_data_size\":64}},"
+        "{\"name\":\"INPUT1\",\"datatype\":\"INT32\",\"shape\":[1,16],\"parameters\":{\"binary_data_size\":64}}],"
+        "\"outputs\":[{\"name\":\"OUTPUT0\",\"parameters\":{\"binary_data\":true}}]}";
+    std::vector<std::string> stream;
+    for (int round = 0; round < 20000; ++round) {
+      std::string m = seeds[next() % 3];
+      const int edits = 1 + static_cast<int>(next() % 4);
+      for (int k = 0; k < edits && !m.empty(); ++k) {
+        const size_t at = next() % m.size();
+        switch (next() % 4) {
+          case 0: m[at] = static_cast<char>(m[at] ^ (1 << (next() % 8))); break;
+          case 1: m[at] = static_cast<char>(next()); break;
+          case 2: m.insert(at, 1, static_cast<char>(next())); break;
+          default: m.erase(at, 1 + next() % 3); break;
+        }
+      }
+      ex.TryGrpc(m, &response);
+      ex.TryGrpcStream(m, &stream);
+      std::string body = http_seed;
+      const size_t json_len = body.size();
+      body.append(128, '\1');
+      const size_t at = next() % json_len;
+      body[at] = static_cast<char>(next() % 3 == 0 ? next() : body[at] ^ (1 << (next() % 7)));
+      ex.TryHttp("simple", "", body, static_cast<int64_t>(next() % 5 == 0 ? next() % 400 : json_len), &headers, &parts);
+    }
+  }
   if (ex.TryHttp("simple", "", "{\"inputs\":[{\"name\":\"INPUT0\"", -1, &headers, &parts)) Fail("truncated JSON accepted");
   if (ex.TryHttp("simple", "", "{\"inputs\":[]}", 400, &headers, &parts)) Fail("header length past the body accepted");
   munmap(mem, 4096);

@@ -648,6 +648,9 @@ def test_both_http_fronts_serve_the_same_surface(impl):
             x = np.arange(300_000, dtype=np.int32).reshape(1, -1)  # 1.2 MB: above the zero-copy threshold
             inp = httpclient.InferInput("INPUT0", list(x.shape), "INT32").set_data_from_numpy(x)
             np.testing.assert_array_equal(c.infer("custom_identity_int32", [inp]).as_numpy("OUTPUT0"), x)
+            x = np.arange(3_000_000, dtype=np.int32).reshape(1, -1)  # 12 MB: the body buffer grows while it arrives
+            inp = httpclient.InferInput("INPUT0", list(x.shape), "INT32").set_data_from_numpy(x)
+            np.testing.assert_array_equal(c.infer("custom_identity_int32", [inp]).as_numpy("OUTPUT0"), x)
             stats = c.get_inference_statistics("simple")["model_stats"][0]
             assert stats["inference_count"] >= 20
             # the same counters in Prometheus text form
