@@ -22,7 +22,8 @@
 //                   passes.
 //   BiasReluMaxPoolKernel  the stem's epilogue folded into its 3x3/2 max pooling.
 //
-// GEMM structure: 4 wavefronts (2x2) or 8 (2x4), block tile BM x BN, K step
+// GEMM structure: 4 wavefronts (2x2), 8 (2x4) or 16 (4x4, 2x8: the 256-wide
+// tiles, one block per CU), block tile BM x BN, K step
 // 64, v_mfma_f32_16x16x32_f16.  The 8-wavefront 128x128 tile (64x32 per wave)
 // keeps twice the waves per SIMD in flight for the same LDS footprint.  The weight tile is the MFMA A operand and the
 // activation tile the B operand, i.e. the wave computes Y^T fragments: each
@@ -154,19 +155,19 @@ struct Pointwise3 {
   _Float16* out;         // [M][kN3] = relu(y x w^T + bias)
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0, bool kHalo = false>
-__global__ __launch_bounds__(128 * kWN, kFuse ? kWN : 1) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0, bool kHalo = false, int kWM = 2>
+__global__ __launch_bounds__(64 * kWM * kWN, kFuse ? kWN : 1) void ConvGemmKernel(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias,
                                                           const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ Y, int M, int N, int K, int relu,
                                                           RowMap map, int tiles_n, int xcd_chunk, unsigned x_bytes,
                                                           int stages, int splits, float* __restrict__ partials,
                                                           unsigned* __restrict__ arrivals, Pointwise2 pw2, Pointwise3 pw3) {
-  constexpr int kW = 2 * kWN;                // wavefronts: 2 along m x kWN along n
+  constexpr int kW = kWM * kWN;              // wavefronts: kWM (2, or 4 for the 16-wave tiles) along m x kWN along n
   constexpr int kT = 64 * kW;                // threads
   constexpr int kAVecs = BM * 8 / kT;        // 16-byte vectors per thread and stage (activation tile)
   constexpr int kWVecs = BN * 8 / kT;        // (weight tile)
-  constexpr int kMI = BM / 32;               // 16-wide fragments per wave along m
+  constexpr int kMI = BM / (16 * kWM);       // 16-wide fragments per wave along m
   constexpr int kNI = BN / (16 * kWN);       // along n
   static_assert(kAVecs >= 1 && kWVecs >= 1 && kNI >= 1, "tile too small for the wave layout");
   // kHalo (3x3, stride 1, pad 1): the activation rows a tile's nine taps touch - the tile's own pixels plus
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(128 * kWN, kFuse ? kWN : 1) void ConvGemmKernel(con
   if constexpr (kHalo) {
 #pragma unroll
     for (int mi = 0; mi < kMI; ++mi) {
-      const int m = m0 + wm * (BM / 2) + mi * 16 + (lane & 15);
+      const int m = m0 + wm * (BM / kWM) + mi * 16 + (lane & 15);
       int img, oh, ow;
       SplitPixel(map, m, small_pixels, img, oh, ow);
       unsigned rows_ok = 0, cols_ok = 0;
@@ -417,11 +418,11 @@ __global__ __launch_bounds__(128 * kWN, kFuse ? kWN : 1) void ConvGemmKernel(con
   // fragment starts at a multiple of 16 rows, and "+4 chunks" is an XOR of 32 halfs
   const int frag_row = lane & 15;
   const int frag_chunk = (lane >> 4) ^ ((frag_row >> 1) & 7);
-  const int xf_off = (wm * (BM / 2) + frag_row) * kBK + frag_chunk * 8;
+  const int xf_off = (wm * (BM / kWM) + frag_row) * kBK + frag_chunk * 8;
   const int wf_off = BM * kBK + (wn * (BN / kWN) + frag_row) * kBK + frag_chunk * 8;
   // halo form: position of the K step being computed
   int cur_c0 = 0, cur_tap = 0, cur_toff = 0, cur_kw = 0;
-  const int h_row = wm * (BM / 2) + (lane & 15);
+  const int h_row = wm * (BM / kWM) + (lane & 15);
   auto compute_tile = [&](int stage) {
     const _Float16* base = stage0 + stage * kStageHalfs;
     if constexpr (kHalo) {
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(128 * kWN, kFuse ? kWN : 1) void ConvGemmKernel(con
       for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(b1r[ni][r]);
 #pragma unroll
       for (int mi = 0; mi < kMI; ++mi) {
-        const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
+        const int m_local = wm * (BM / kWM) + mi * 16 + (lane & 15);
         half4 packed;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(128 * kWN, kFuse ? kWN : 1) void ConvGemmKernel(con
         }
 #pragma unroll
         for (int mi = 0; mi < kMI; ++mi) {
-          const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
+          const int m_local = wm * (BM / kWM) + mi * 16 + (lane & 15);
           half4 packed;
 #pragma unroll
           for (int r = 0; r < 4; ++r) packed[r] = static_cast<_Float16>(acc2[ni][mi][r] + b[r]);
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(128 * kWN, kFuse ? kWN : 1) void ConvGemmKernel(con
         for (int r = 0; r < 4; ++r) b[r] = static_cast<float>(b3r[ni][r]);
 #pragma unroll
         for (int mi = 0; mi < kMI; ++mi) {
-          const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
+          const int m_local = wm * (BM / kWM) + mi * 16 + (lane & 15);
           half4 packed;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(128 * kWN, kFuse ? kWN : 1) void ConvGemmKernel(con
     }
 #pragma unroll
     for (int mi = 0; mi < kMI; ++mi) {
-      const int m_local = wm * (BM / 2) + mi * 16 + (lane & 15);
+      const int m_local = wm * (BM / kWM) + mi * 16 + (lane & 15);
       half4 packed;
 #pragma unroll
       for (int r = 0; r < 4; ++r) packed[r] = static_cast<_Float16>(acc[ni][mi][r] + b[r]);
@@ -1226,7 +1227,7 @@ struct SplitK {
   int arrival_slots;
 };
 
-template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0, bool kHalo = false>
+template <int BM, int BN, int kWN, bool kSpatial, bool kGlds, bool kFuse = false, int kN3 = 0, int kXS = 0, bool kHalo = false, int kWM = 2>
 int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, const _Float16* residual, _Float16* y,
                   int M, int N, int K, int relu, const RowMap& map, unsigned x_bytes, int stages, const SplitK& sk,
                   hipStream_t st, const Pointwise2& pw2 = Pointwise2{nullptr, nullptr, 0, nullptr},
@@ -1260,10 +1261,11 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   const int ktiles = (ktiles_all + splits - 1) / splits;
   if (!kGlds) stages = 2;
   if (stages > ktiles) stages = ktiles;
+  while (stages > 2 && static_cast<size_t>(stages) * (BM + BN) * kBK * sizeof(_Float16) > 160 * 1024) --stages;  // LDS of one CU
   size_t lds_bytes = static_cast<size_t>(stages) * (BM + BN) * kBK * sizeof(_Float16);
   if (kHalo) {
     if (map.ksize != 3 || map.stride != 1 || map.pad != 1 || splits != 1) return -2;
-    const size_t halo_rows = static_cast<size_t>((BM + 2 * map.in_w + 2) / (8 * 2 * kWN) + 1) * (8 * 2 * kWN);
+    const size_t halo_rows = static_cast<size_t>((BM + 2 * map.in_w + 2) / (8 * kWM * kWN) + 1) * (8 * kWM * kWN);
     lds_bytes = (static_cast<size_t>(map.cin / kBK) * halo_rows + static_cast<size_t>(stages) * BN) * kBK * sizeof(_Float16);
     if (lds_bytes > 160 * 1024) return -2;
   }
@@ -1284,11 +1286,11 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (c_bytes > lds_bytes) lds_bytes = c_bytes;
   if (lds_bytes > 64 * 1024) {
     // above the default dynamic-LDS limit: raise it once per kernel instantiation
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS, kHalo>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS, kHalo, kWM>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
   }
-  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS, kHalo>), dim3(blocks, splits), dim3(128 * kWN), lds_bytes, st,
+  hipLaunchKernelGGL((ConvGemmKernel<BM, BN, kWN, kSpatial, kGlds, kFuse, kN3, kXS, kHalo, kWM>), dim3(blocks, splits), dim3(64 * kWM * kWN), lds_bytes, st,
                      x, w, bias, residual, y, M, N, K, relu, map, tiles_n, xcd_chunk, x_bytes, stages, splits, sk.partials,
                      sk.arrivals, pw2, pw3);
   const hipError_t e = hipGetLastError();
@@ -1302,7 +1304,8 @@ extern "C" {
 // x: [batch,in_h,in_w,cin] fp16, w: [cout][ksize][ksize][cin] fp16 (the memory of
 // a channels-last [cout,cin,ksize,ksize] weight), y: [batch,oh,ow,cout].
 // variant: low 4 bits 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile (4 wavefronts),
-// 4 = 128x128, 5 = 256x128 (8 wavefronts);
+// 4 = 128x128, 5 = 256x128, 6 = 128x64, 7 = 64x64, 8 = 128x256 (8 wavefronts);
+// 9 = 256x128, 10 = 256x256, 11 = 128x256 (16 wavefronts);
 // bit 4 selects register staging; bits 5-6 the number of LDS stages (2 or 3).
 // splits: 1 = no split-K, 0 = automatic, n > 1 = exactly n.  partials / arrivals: the split-K
 // workspace (device memory; `arrivals` zero-filled once, the kernel leaves it zeroed) -
@@ -1353,12 +1356,16 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
     else variant = (cout % 128 != 0 && K >= 256) ? 7 : 2;
   }
   if ((variant == 1 || variant == 4 || variant == 5) && cout % 128 != 0) return -2;
-  if (variant == 8 && cout % 256 != 0) return -2;
+  if ((variant == 8 || variant == 10 || variant == 11) && cout % 256 != 0) return -2;
+  if (variant == 9 && cout % 128 != 0) return -2;
+  if (variant >= 9 && staging) return -2;  // the 16-wavefront tiles exist in the DMA-staged form only
   if (stages != 2 && stages != 3) {
     // a third stage hides more DMA latency but costs LDS: take it only when the grid is
     // too small for the LDS limit on resident blocks to bind
-    const int bm = (variant == 3 || variant == 7) ? 64 : (variant == 5 ? 256 : 128);
-    const int bn = (variant == 2 || variant == 3 || variant == 6 || variant == 7) ? 64 : (variant == 8 ? 256 : 128);
+    const int bm = (variant == 3 || variant == 7) ? 64 : ((variant == 5 || variant == 9 || variant == 10) ? 256 : 128);
+    const int bn = (variant == 2 || variant == 3 || variant == 6 || variant == 7)
+                       ? 64
+                       : ((variant == 8 || variant == 10 || variant == 11) ? 256 : 128);
     const long long blocks = static_cast<long long>((M + bm - 1) / bm) * (cout / bn);
     const long long per_cu_wanted = (blocks + 255) / 256;
     const long long per_cu_with_3 = (160 * 1024) / (3 * (bm + bn) * kBK * 2);
@@ -1378,6 +1385,11 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
                       : LaunchConvGemm<BM_, BN_, WN_, true, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, sk, st))  \
            : (staging ? LaunchConvGemm<BM_, BN_, WN_, false, false>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, sk, st) \
                       : LaunchConvGemm<BM_, BN_, WN_, false, true>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, stages, sk, st)))
+#define TCA_DISPATCH16(BM_, BN_, WN_, WM_)                                                                                   \
+  (spatial ? LaunchConvGemm<BM_, BN_, WN_, true, true, false, 0, 0, false, WM_>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, \
+                                                                                stages, sk, st)                               \
+           : LaunchConvGemm<BM_, BN_, WN_, false, true, false, 0, 0, false, WM_>(xp, wp, bp, rp, yp, M, cout, K, relu, map, x_bytes, \
+                                                                                 stages, sk, st))
   switch (variant) {
     case 1: return TCA_DISPATCH(128, 128, 2);
     case 2: return TCA_DISPATCH(128, 64, 2);
@@ -1387,9 +1399,15 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
     case 6: return TCA_DISPATCH(128, 64, 4);   // 8 wavefronts, 64x16 per wave
     case 7: return TCA_DISPATCH(64, 64, 4);    // 8 wavefronts, 32x16 per wave
     case 8: return TCA_DISPATCH(128, 256, 4);  // 8 wavefronts, 64x64 per wave
+    // 16 wavefronts (4 per SIMD from ONE block): the operand bytes a CU takes in per FLOP are those of the
+    // large tile, the waves in flight those of two co-resident 128x128 blocks
+    case 9: return TCA_DISPATCH16(256, 128, 4, 4);   // 4x4 waves, 64x32 per wave
+    case 10: return TCA_DISPATCH16(256, 256, 4, 4);  // 4x4 waves, 64x64 per wave
+    case 11: return TCA_DISPATCH16(128, 256, 8, 2);  // 2x8 waves, 64x32 per wave
     default: return -3;
   }
 #undef TCA_DISPATCH
+#undef TCA_DISPATCH16
 }
 
 // y = act(conv1x1(relu(conv(x, w1) + bias1), w2) + bias2 (+ residual)) in ONE kernel: the middle

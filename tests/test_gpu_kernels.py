@@ -274,7 +274,7 @@ def _nhwc(t):
 
 
 @pytest.mark.parametrize("variant", ["auto", "128x128", "128x64", "64x64", "128x128w8", "256x128w8", "128x64w8",
-                                     "64x64w8", "128x256w8"])
+                                     "64x64w8", "128x256w8", "256x128w16", "256x256w16", "128x256w16"])
 @pytest.mark.parametrize("shape", [
     # batch, H, W, Cin, Cout, stride, residual, relu
     (2, 56, 56, 64, 256, 1, True, True),
@@ -287,7 +287,7 @@ def test_conv1x1_mfma_matches_fp32_reference(torch, shape, variant):
     from triton_client_amd.ops import conv
 
     b, h, w, cin, cout, stride, with_res, relu = shape
-    if variant.endswith("x256w8") and cout % 256:
+    if "x256w" in variant and cout % 256:
         pytest.skip("tile wider than the layer")
     gen = torch.Generator(device="cuda").manual_seed(cin + cout + h)
     x = _nhwc(torch.randn(b, cin, h, w, device="cuda", generator=gen).half())
@@ -317,7 +317,9 @@ def test_conv1x1_exact_integer_operand_maps(torch):
     wt[5, 7] = 9.0
     bias = torch.arange(cout, device="cuda").half()
     for staging in ("lds2", "lds3", "reg"):
-        for variant in ("128x128", "128x64", "64x64", "128x128w8", "256x128w8", "128x64w8", "64x64w8"):
+        for variant in ("128x128", "128x64", "64x64", "128x128w8", "256x128w8", "128x64w8", "64x64w8", "256x128w16"):
+            if staging == "reg" and variant.endswith("w16"):
+                continue  # the 16-wavefront tiles are DMA-staged only
             got = conv.conv1x1(x, wt, bias, None, relu=False, variant=variant, staging=staging)
             ref = torch.nn.functional.conv2d(x.float(), wt.float().reshape(cout, cin, 1, 1), bias.float())
             assert torch.equal(got.float(), ref), (variant, staging)
@@ -383,8 +385,25 @@ def test_conv3x3_exact_integer_taps(torch):
     wt[7, 70, 2, 0] = 3.0
     ref = torch.nn.functional.conv2d(x.float(), wt.float(), None, stride=2, padding=1)
     for staging in ("lds2", "lds3", "reg"):
-        for variant in ("128x128", "128x64", "64x64", "128x128w8", "256x128w8", "128x64w8", "64x64w8"):
+        for variant in ("128x128", "128x64", "64x64", "128x128w8", "256x128w8", "128x64w8", "64x64w8", "256x128w16"):
+            if staging == "reg" and variant.endswith("w16"):
+                continue
             got = conv.conv2d(x, wt, None, None, relu=False, stride=2, padding=1, variant=variant, staging=staging)
+            assert torch.equal(got.float(), ref), (variant, staging)
+
+
+def test_conv3x3_sixteen_wave_tiles_exact(torch):
+    """The 16-wavefront tiles (four wave rows) on integer data: 3x3, ragged last tile, 256 output channels."""
+    from triton_client_amd.ops import conv
+
+    x = _nhwc(torch.randint(-2, 3, (3, 128, 14, 14), device="cuda").half())
+    wt = _nhwc(torch.randint(-1, 2, (256, 128, 3, 3), device="cuda").half())
+    wt[200, 70, 2, 0] = 3.0
+    bias = torch.arange(256, device="cuda").half()
+    ref = torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=1, padding=1)
+    for staging in ("lds2", "lds3"):
+        for variant in ("256x128w16", "256x256w16", "128x256w16"):
+            got = conv.conv2d(x, wt, bias, None, relu=False, stride=1, padding=1, variant=variant, staging=staging)
             assert torch.equal(got.float(), ref), (variant, staging)
 
 

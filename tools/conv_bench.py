@@ -26,7 +26,8 @@ LAYERS_3X3 = [(56, 56, 64, 1), (56, 56, 128, 2), (28, 28, 128, 1), (28, 28, 256,
               (14, 14, 512, 2), (7, 7, 512, 1)]
 
 
-MFMA_VARIANTS = ("128x64", "64x64", "128x128w8", "128x64w8", "64x64w8", "128x256w8")
+MFMA_VARIANTS = tuple(os.environ["TCA_BENCH_VARIANTS"].split(",")) if os.environ.get("TCA_BENCH_VARIANTS") else (
+    "128x64", "64x64", "128x128w8", "128x64w8", "64x64w8", "128x256w8", "256x128w16", "128x256w16")
 
 
 def main():
@@ -105,7 +106,7 @@ def main():
             t = totals.setdefault(b, {"eager": 0.0, "lib+ep": 0.0, "mfma_best": 0.0, "best": 0.0})
             t["eager"] += times["eager"]
             t["lib+ep"] += times["lib+ep"]
-            mf = min(times[k] for k in MFMA_VARIANTS if times[k] == times[k])
+            mf = min((times[k] for k in MFMA_VARIANTS if times[k] == times[k]), default=times["lib+ep"])
             t["mfma_best"] += mf
             t["best"] += min(mf, times["lib+ep"])
         for (h, w, c, stride) in LAYERS_3X3:

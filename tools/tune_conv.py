@@ -18,6 +18,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = ("128x128w8", "128x64", "64x64", "128x64w8", "64x64w8")
+# Wider tiles (more FLOP per operand byte a CU takes in).  Alone on the GPU they win single layers by 3-10 %, but a
+# table that includes them measured 1-2.5 % slower over the whole forward pass and no different under serving load
+# (their few, long blocks leave CUs idle that the 128x128 launch fills): opt-in with --wide.
+WIDE_VARIANTS = ("128x256w8", "256x128w16", "128x256w16", "256x256w16")
 # (H, W, Cin, Mid, Cout, stride, next 1x1 outputs or 0) of the blocks the fused kernel covers
 FUSED_BLOCKS = [(56, 56, 64, 64, 256, 1, 64), (56, 56, 64, 64, 256, 1, 128), (56, 56, 128, 128, 512, 2, 128),
                 (28, 28, 128, 128, 512, 1, 128), (28, 28, 128, 128, 512, 1, 0)]
@@ -28,7 +32,9 @@ def main():
     ap.add_argument("--out", default="gpurun_out/conv_tuning_gfx950.json")
     ap.add_argument("--batches", default=",".join(str(b) for b in range(8, 129, 8)))
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--wide", action="store_true", help="also try the 256-wide and 16-wavefront tiles")
     args = ap.parse_args()
+    variants = VARIANTS + (WIDE_VARIANTS if args.wide else ())
     import torch
 
     from conv_bench import LAYERS, LAYERS_3X3
@@ -72,8 +78,8 @@ def main():
             res = nhwc(torch.randn(batch, cout, oh, ow, device=dev).half()) if with_res else None
             out = nhwc(torch.empty(batch, cout, oh, ow, device=dev, dtype=torch.float16))
             times = {}
-            for variant in VARIANTS:
-                if "x128" in variant and cout % 128:
+            for variant in variants:
+                if ("x128" in variant and cout % 128) or ("x256" in variant and cout % 256):
                     continue
                 times[variant] = graph_time(lambda v=variant: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride,
                                                                           padding=pad, variant=v, out=out))
