@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--out", default="gpurun_out/conv_tuning_gfx950.json")
     ap.add_argument("--batches", default=",".join(str(b) for b in range(8, 129, 8)))
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="time every candidate on this many streams at once (2: the server's two execution instances)")
     ap.add_argument("--wide", action="store_true", help="also try the 256-wide and 16-wavefront tiles")
     args = ap.parse_args()
     variants = VARIANTS + (WIDE_VARIANTS if args.wide else ())
@@ -43,7 +45,38 @@ def main():
     dev = torch.device("cuda:0")
     stream = torch.cuda.Stream()
 
+    streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+
+    def graph_time_concurrent(fn):
+        """us per call with the same work replayed on every stream at once: what a layer costs while another
+        execution instance keeps the rest of the GPU busy (the condition the server runs under)."""
+        import time
+
+        graphs = []
+        for st in streams:
+            with torch.cuda.stream(st):
+                fn()
+                st.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    for _ in range(args.reps):
+                        fn()
+                g.replay()
+                st.synchronize()
+                graphs.append(g)
+        rounds = 6
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            for st, g in zip(streams, graphs):
+                with torch.cuda.stream(st):
+                    g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e6 / (rounds * args.reps * len(streams))
+
     def graph_time(fn):
+        if len(streams) > 1:
+            return graph_time_concurrent(fn)
         with torch.cuda.stream(stream):
             fn()
             stream.synchronize()
