@@ -1266,7 +1266,11 @@ int LaunchConvGemm(const _Float16* x, const _Float16* w, const _Float16* bias, c
   if (kHalo) {
     if (map.ksize != 3 || map.stride != 1 || map.pad != 1 || splits != 1) return -2;
     const size_t halo_rows = static_cast<size_t>((BM + 2 * map.in_w + 2) / (8 * kWM * kWN) + 1) * (8 * kWM * kWN);
-    lds_bytes = (static_cast<size_t>(map.cin / kBK) * halo_rows + static_cast<size_t>(stages) * BN) * kBK * sizeof(_Float16);
+    auto halo_lds = [&](int st) {
+      return (static_cast<size_t>(map.cin / kBK) * halo_rows + static_cast<size_t>(st) * BN) * kBK * sizeof(_Float16);
+    };
+    while (stages > 2 && halo_lds(stages) > 160 * 1024) --stages;
+    lds_bytes = halo_lds(stages);
     if (lds_bytes > 160 * 1024) return -2;
   }
   size_t c_bytes = static_cast<size_t>(BM) * (BN + 8) * sizeof(_Float16);
@@ -1305,7 +1309,7 @@ extern "C" {
 // a channels-last [cout,cin,ksize,ksize] weight), y: [batch,oh,ow,cout].
 // variant: low 4 bits 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile (4 wavefronts),
 // 4 = 128x128, 5 = 256x128, 6 = 128x64, 7 = 64x64, 8 = 128x256 (8 wavefronts);
-// 9 = 256x128, 10 = 256x256, 11 = 128x256 (16 wavefronts);
+// 9 = 256x128, 10 = 256x256, 11 = 128x256 (16 wavefronts); 12 = 128x256, 13 = 128x128 in the halo form (3x3 stride 1 pad 1);
 // bit 4 selects register staging; bits 5-6 the number of LDS stages (2 or 3).
 // splits: 1 = no split-K, 0 = automatic, n > 1 = exactly n.  partials / arrivals: the split-K
 // workspace (device memory; `arrivals` zero-filled once, the kernel leaves it zeroed) -
@@ -1356,8 +1360,14 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
     else variant = (cout % 128 != 0 && K >= 256) ? 7 : 2;
   }
   if ((variant == 1 || variant == 4 || variant == 5) && cout % 128 != 0) return -2;
-  if ((variant == 8 || variant == 10 || variant == 11) && cout % 256 != 0) return -2;
-  if (variant == 9 && cout % 128 != 0) return -2;
+  if ((variant == 8 || variant == 10 || variant == 11 || variant == 12) && cout % 256 != 0) return -2;
+  if ((variant == 9 || variant == 13) && cout % 128 != 0) return -2;
+  if (variant == 12 || variant == 13) {
+    // one block per CU whatever the grid: the halo takes most of the LDS; no split-K in this form
+    if (ksize != 3 || stride != 1 || pad != 1) return -2;
+    splits = 1;
+    stages = 3;
+  }
   if (variant >= 9 && staging) return -2;  // the 16-wavefront tiles exist in the DMA-staged form only
   if (stages != 2 && stages != 3) {
     // a third stage hides more DMA latency but costs LDS: take it only when the grid is
@@ -1365,7 +1375,7 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
     const int bm = (variant == 3 || variant == 7) ? 64 : ((variant == 5 || variant == 9 || variant == 10) ? 256 : 128);
     const int bn = (variant == 2 || variant == 3 || variant == 6 || variant == 7)
                        ? 64
-                       : ((variant == 8 || variant == 10 || variant == 11) ? 256 : 128);
+                       : ((variant == 8 || variant == 10 || variant == 11 || variant == 12) ? 256 : 128);
     const long long blocks = static_cast<long long>((M + bm - 1) / bm) * (cout / bn);
     const long long per_cu_wanted = (blocks + 255) / 256;
     const long long per_cu_with_3 = (160 * 1024) / (3 * (bm + bn) * kBK * 2);
@@ -1404,6 +1414,17 @@ int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, 
     case 9: return TCA_DISPATCH16(256, 128, 4, 4);   // 4x4 waves, 64x32 per wave
     case 10: return TCA_DISPATCH16(256, 256, 4, 4);  // 4x4 waves, 64x64 per wave
     case 11: return TCA_DISPATCH16(128, 256, 8, 2);  // 2x8 waves, 64x32 per wave
+    // Halo form of a plain 3x3 / stride 1 / pad 1 convolution: the tile's input rows are brought into LDS once
+    // and the K loop streams weights only (about half the operand bytes per FLOP of the tap-by-tap form);
+    // layers whose halo does not fit LDS are refused (-2)
+    case 12:
+      return spatial && !staging ? LaunchConvGemm<128, 256, 4, true, true, false, 0, 0, true>(xp, wp, bp, rp, yp, M, cout, K, relu,
+                                                                                          map, x_bytes, stages, sk, st)
+                                 : -2;
+    case 13:
+      return spatial && !staging ? LaunchConvGemm<128, 128, 4, true, true, false, 0, 0, true>(xp, wp, bp, rp, yp, M, cout, K, relu,
+                                                                                          map, x_bytes, stages, sk, st)
+                                 : -2;
     default: return -3;
   }
 #undef TCA_DISPATCH

@@ -407,6 +407,29 @@ def test_conv3x3_sixteen_wave_tiles_exact(torch):
             assert torch.equal(got.float(), ref), (variant, staging)
 
 
+@pytest.mark.parametrize("shape", [(3, 128, 14, 14, 256), (2, 256, 14, 14, 256), (1, 64, 28, 28, 128), (5, 64, 7, 7, 256)])
+def test_conv3x3_plain_halo_form_exact(torch, shape):
+    """Halo form of the plain 3x3 convolution (input rows in LDS once, the K loop streams weights): integer data,
+    image borders inside a tile (several images per tile), ragged last tile, one to four 64-channel slices."""
+    from triton_client_amd.ops import conv
+
+    b, cin, h, w, cout = shape
+    gen = torch.Generator(device="cuda").manual_seed(b * 1000 + cin + cout)
+    x = _nhwc(torch.randint(-2, 3, (b, cin, h, w), device="cuda", generator=gen).half())
+    wt = _nhwc(torch.randint(-1, 2, (cout, cin, 3, 3), device="cuda", generator=gen).half())
+    wt[cout - 3, cin - 5, 2, 0] = 3.0
+    bias = torch.arange(cout, device="cuda").half()
+    res = _nhwc(torch.randint(-4, 5, (b, cout, h, w), device="cuda", generator=gen).half())
+    ref = (torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=1, padding=1) + res.float()).clamp_min(0)
+    for variant in ("128x256halo", "128x128halo"):
+        if variant == "128x256halo" and cout % 256:
+            continue
+        got = conv.conv2d(x, wt, bias, res, relu=True, stride=1, padding=1, variant=variant)
+        assert torch.equal(got.float(), ref), variant
+    with pytest.raises(RuntimeError):  # stride 2 has no halo form
+        conv.conv2d(x, wt, bias, None, relu=True, stride=2, padding=1, variant="128x128halo")
+
+
 @pytest.mark.parametrize("staging", ["lds2", "lds3", "reg"])
 def test_conv_split_k_exact_and_repeatable(torch, staging):
     """Split-K (several blocks per output tile, partials summed by the block that arrives

@@ -22,6 +22,7 @@ VARIANTS = ("128x128w8", "128x64", "64x64", "128x64w8", "64x64w8")
 # table that includes them measured 1-2.5 % slower over the whole forward pass and no different under serving load
 # (their few, long blocks leave CUs idle that the 128x128 launch fills): opt-in with --wide.
 WIDE_VARIANTS = ("128x256w8", "256x128w16", "128x256w16", "256x256w16")
+HALO_VARIANTS = ("128x256halo", "128x128halo")  # plain 3x3 / stride 1 only; refused where the halo exceeds LDS
 # (H, W, Cin, Mid, Cout, stride, next 1x1 outputs or 0) of the blocks the fused kernel covers
 FUSED_BLOCKS = [(56, 56, 64, 64, 256, 1, 64), (56, 56, 64, 64, 256, 1, 128), (56, 56, 128, 128, 512, 2, 128),
                 (28, 28, 128, 128, 512, 1, 128), (28, 28, 128, 128, 512, 1, 0)]
@@ -111,9 +112,12 @@ def main():
             res = nhwc(torch.randn(batch, cout, oh, ow, device=dev).half()) if with_res else None
             out = nhwc(torch.empty(batch, cout, oh, ow, device=dev, dtype=torch.float16))
             times = {}
-            for variant in variants:
+            for variant in variants + (HALO_VARIANTS if args.wide and k == 3 and stride == 1 else ()):
                 if ("x128" in variant and cout % 128) or ("x256" in variant and cout % 256):
                     continue
+                if variant in HALO_VARIANTS and ((cin // 64) * (((128 + 2 * w + 2) // 64 + 1) * 64)
+                                                 + 2 * int(variant[4:7])) * 128 > 160 * 1024:
+                    continue  # halo rows + two weight stages do not fit the CU's LDS
                 times[variant] = graph_time(lambda v=variant: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride,
                                                                           padding=pad, variant=v, out=out))
             auto = graph_time(lambda: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride, padding=pad,

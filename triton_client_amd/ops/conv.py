@@ -20,7 +20,8 @@ from __future__ import annotations
 from ._device import check, lib
 
 VARIANTS = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3, "128x128w8": 4, "256x128w8": 5,
-            "128x64w8": 6, "64x64w8": 7, "128x256w8": 8, "256x128w16": 9, "256x256w16": 10, "128x256w16": 11}
+            "128x64w8": 6, "64x64w8": 7, "128x256w8": 8, "256x128w16": 9, "256x256w16": 10, "128x256w16": 11,
+            "128x256halo": 12, "128x128halo": 13}
 # operand staging of the GEMM kernel: "lds" = direct global->LDS DMA (default),
 # "reg" = through registers + ds_write (kept for A/B measurements)
 _REG_STAGING = 16
