@@ -148,3 +148,65 @@ def test_ensemble_requests_with_fresh_tensors_leave_memory_flat():
             np.testing.assert_allclose(got, first, rtol=1e-2, atol=1e-2)
             assert net.graph_count() == graphs
             assert torch.cuda.memory_reserved() - reserved <= (8 << 20)
+
+
+def _plan_counters(served):
+    import urllib.request
+
+    text = urllib.request.urlopen(f"http://{served.http_url}/metrics", timeout=5).read().decode()
+    return {line.split()[0]: int(line.split()[1]) for line in text.splitlines() if line.startswith("tca_request_plan_")}
+
+
+def test_repeated_messages_run_from_their_plan_on_fresh_contents(served):
+    """The same raw request message again and again is queued from its stored plan: every repeat still
+    reads what is in the region NOW and writes its own answer, and a region that comes back under the
+    same name with other memory behind it gets a new plan."""
+    import tritonclient.grpc as g
+    import tritonclient.utils.cuda_shared_memory as hipshm
+
+    rng = np.random.default_rng(7)
+    x1 = rng.standard_normal((B, 3, 224, 224)).astype(np.float16)
+    x2 = rng.standard_normal((B, 3, 224, 224)).astype(np.float16)
+
+    def read(handle):
+        return hipshm.get_contents_as_numpy(handle, np.float32, [B, 1000]).copy()
+
+    with g.InferenceServerClient(served.grpc_url) as c:
+        def wire(x):  # reference: the same tensors in the message itself
+            inp = g.InferInput("input", [B, 3, 224, 224], "FP16")
+            inp.set_data_from_numpy(x)
+            return c.infer("resnet50", [inp]).as_numpy("output")
+
+        ref1, ref2 = wire(x1), wire(x2)
+        assert np.abs(ref1 - ref2).max() > 1e-2
+        (hin, hout), = _make_regions(hipshm, c, "plan", 1, x1)
+        before = _plan_counters(served)
+        ins, outs = _request(g, "plan", 0)
+        for x, ref in ((x1, ref1), (x2, ref2), (x1, ref1), (x2, ref2)):
+            hipshm.set_shared_memory_region(hin, [x])
+            hipshm.set_shared_memory_region(hout, [np.full((B, 1000), -7.0, np.float32)])
+            c.infer("resnet50", ins, outputs=outs)
+            np.testing.assert_allclose(read(hout), ref, rtol=1e-2, atol=1e-2)
+        mid = _plan_counters(served)
+        assert mid["tca_request_plan_stored_total"] == before["tca_request_plan_stored_total"] + 1
+        assert mid["tca_request_plan_hits_total"] == before["tca_request_plan_hits_total"] + 3
+        # the same names, other memory: the old plan must not be used (its views alias the old mapping)
+        c.unregister_cuda_shared_memory("plan_in0")
+        c.unregister_cuda_shared_memory("plan_out0")
+        hipshm.set_shared_memory_region(hout, [np.full((B, 1000), -7.0, np.float32)])
+        hin2 = hipshm.create_shared_memory_region("plan_in0_b", IN_BYTES, 0)
+        hout2 = hipshm.create_shared_memory_region("plan_out0_b", OUT_BYTES, 0)
+        hipshm.set_shared_memory_region(hin2, [x2])
+        c.register_cuda_shared_memory("plan_in0", hipshm.get_raw_handle(hin2), 0, IN_BYTES)
+        c.register_cuda_shared_memory("plan_out0", hipshm.get_raw_handle(hout2), 0, OUT_BYTES)
+        for _ in range(2):
+            c.infer("resnet50", ins, outputs=outs)
+            np.testing.assert_allclose(read(hout2), ref2, rtol=1e-2, atol=1e-2)
+        assert np.all(read(hout) == -7.0)  # nothing wrote through the old mapping
+        after = _plan_counters(served)
+        assert after["tca_request_plan_stored_total"] == mid["tca_request_plan_stored_total"] + 1
+        assert after["tca_request_plan_hits_total"] == mid["tca_request_plan_hits_total"] + 1
+        c.unregister_cuda_shared_memory("plan_in0")
+        c.unregister_cuda_shared_memory("plan_out0")
+        for h in (hin, hout, hin2, hout2):
+            hipshm.destroy_shared_memory_region(h)

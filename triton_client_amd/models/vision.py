@@ -196,6 +196,10 @@ class ResNet50(Model):
     max_batch_size = 128
     dynamic_batching = True
     max_queue_delay_us = 0  # launch as soon as the GPU has room; batches form while it is busy
+    # ... and while every execution instance still has a batch to run, a batch that is not full may wait this
+    # long for more requests (measured at concurrency 64: every merged batch full instead of four in five,
+    # 74-75k -> 77.5k infer/s, p99 10.0 -> 7.0 ms)
+    fill_window_us = 600
     # batch sizes whose HIP graphs are captured at load time (the batcher merges
     # concurrent requests, so totals other than the request batch show up)
     warmup_batches = (8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128)

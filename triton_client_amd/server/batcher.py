@@ -51,7 +51,7 @@ def _profiled(fn, tag):
 
 class _Item:
     __slots__ = ("req", "inputs", "batch", "stable", "requested", "ctx", "stats", "t_arrive", "version", "done",
-                 "response", "error", "t_queued", "callback", "gap_ns", "release")
+                 "response", "error", "t_queued", "callback", "gap_ns", "release", "dests")
 
     def __init__(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback=None):
         self.req, self.inputs, self.batch, self.stable = req, inputs, batch, stable
@@ -64,6 +64,7 @@ class _Item:
         self.t_queued = time.perf_counter_ns()
         self.gap_ns = 1 << 62  # time since the previous arrival for the same model (set by the batcher)
         self.release = None  # gives back the request's shared-memory region leases
+        self.dests = None  # output name -> destination view in a device region, when the submitter knows them already
 
     def finish(self):
         """Hand the outcome to whoever submitted the request.  The GPU work and the copies of
@@ -97,6 +98,9 @@ class DynamicBatcher:
         self.burst_gap_s = float(os.environ.get("TCA_BURST_GAP_US", getattr(self.model, "burst_gap_us", 300))) / 1e6
         self.burst_window_s = float(os.environ.get("TCA_BURST_WINDOW_US", getattr(self.model, "burst_window_us",
                                                                                   100))) / 1e6
+        # While every execution instance has at least one batch enqueued, a batch that is not full yet may
+        # wait this long for more requests (no GPU time is lost: its instance is busy anyway).
+        self.fill_window_s = float(os.environ.get("TCA_FILL_WINDOW_US", getattr(self.model, "fill_window_us", 0))) / 1e6
         self._last_arrival_ns = 0
         self._last_done = (0, 1)  # (time, requests) of the batch that completed last
         # Execution instances of the model (own HIP stream + own captured graphs each):
@@ -105,6 +109,8 @@ class DynamicBatcher:
         self._busy = [0] * self.instances  # batches enqueued per instance (batcher adds, completers subtract)
         self.split_min_batch = int(os.environ.get("TCA_SPLIT_MIN_BATCH", getattr(self.model, "split_min_batch", 16)))
         self._busy_lock = threading.Lock()
+        self._pins = {}  # input address of a single zero-copy request -> instance that captured its graph first
+        self._launch_hist = {} if os.environ.get("TCA_BATCHER_STATS") else None
         # per instance: [ring of [pinned uint8 buffer, event of its last H2D copy, bytes used], next entry]
         self._stagers = [None] * self.instances  # per instance: native wire stager (pinned ring + copy stream)
         self.q = queue.Queue()
@@ -154,15 +160,45 @@ class DynamicBatcher:
     def _stream_of(self, inst):
         return self.model.stream_of(inst) if self.instances > 1 else self.model.stream
 
+    def _note_launch(self, inst, total):
+        """Developer aid (TCA_BATCHER_STATS=<file>): how many batches each instance already had enqueued
+        when a batch was launched on it, and the merged batch sizes; written when the batcher stops."""
+        h = self._launch_hist
+        key = (self._busy[inst] - 1, sum(self._busy) - 1, total)
+        h[key] = h.get(key, 0) + 1
+
+    def _dump_stats(self):
+        path = os.environ.get("TCA_BATCHER_STATS")
+        if not path or not self._launch_hist:
+            return
+        own, everywhere, sizes = {}, {}, {}
+        for (mine, all_, total), n in self._launch_hist.items():
+            own[mine] = own.get(mine, 0) + n
+            everywhere[all_] = everywhere.get(all_, 0) + n
+            sizes[total] = sizes.get(total, 0) + n
+        with open(path, "a") as fh:
+            fh.write(f"model {self.model.name}: launches {sum(own.values())}\n")
+            fh.write(f"  batches already enqueued on the chosen instance: {dict(sorted(own.items()))}\n")
+            fh.write(f"  batches already enqueued on all instances: {dict(sorted(everywhere.items()))}\n")
+            fh.write(f"  merged batch sizes: {dict(sorted(sizes.items()))}\n")
+
     def _pick_instance(self, hint=None):
         """Instance for the next batch: the one with the fewest batches enqueued.
-        ``hint`` (an address) pins single zero-copy requests to one instance, so
-        each client region is captured into one graph, not one per instance."""
+        ``hint`` (an address) keeps single zero-copy requests on the instance that already
+        holds a captured graph for that client region while that instance is not the busier one."""
         with self._busy_lock:
+            inst = min(range(self.instances), key=self._busy.__getitem__)
             if hint is not None:
-                inst = (hint >> 12) % self.instances
-            else:
-                inst = min(range(self.instances), key=self._busy.__getitem__)
+                # the instance this address ran on first, unless another one has less to do right now (two
+                # serial clients then run side by side instead of taking turns on one instance; address
+                # bits would put every 2 MiB-aligned IPC mapping on instance 0)
+                pinned = self._pins.get(hint)
+                if pinned is None:
+                    if len(self._pins) >= 4096:
+                        self._pins.clear()
+                    pinned = self._pins[hint] = inst
+                if self._busy[pinned] <= self._busy[inst]:
+                    inst = pinned
             self._busy[inst] += 1
         return inst
 
@@ -172,6 +208,7 @@ class DynamicBatcher:
         self._inflight.release()
 
     def stop(self):
+        self._dump_stats()
         self._stop = True
         self.q.put(None)
         for c in self.completions:
@@ -188,11 +225,12 @@ class DynamicBatcher:
             raise item.error
         return item.response
 
-    def submit_async(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback):
+    def submit_async(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback, dests=None):
         """Queue a request and return at once; ``callback(response, error)`` runs
         on the completer thread (or the batcher thread when the launch fails)."""
         item = _Item(req, inputs, max(1, batch), stable, requested, ctx, stats, t_arrive, version, callback)
         item.release = self.core.release_request
+        item.dests = dests
         self._stamp(item)
         self.q.put(item)
 
@@ -235,12 +273,17 @@ class DynamicBatcher:
                     # part of a burst, or the first requests coming back after a batch of
                     # several was answered: more is about to arrive
                     deadline = max(deadline, t_first + self.burst_window_s)
-                remaining = deadline - time.perf_counter()
+                filling = self.fill_window_s > 0 and min(self._busy) >= 1
+                # every instance still has a batch to run: nothing idles while this one fills up; looked at
+                # again every 200 us, so an instance that runs out of work gets this batch at once
+                remaining = (max(deadline, t_first + self.fill_window_s) if filling else deadline) - time.perf_counter()
                 if remaining <= 0:
                     break
                 try:
-                    nxt = self.q.get(timeout=remaining)
+                    nxt = self.q.get(timeout=min(remaining, 0.0002) if filling else remaining)
                 except queue.Empty:
+                    if filling:
+                        continue
                     break
             if nxt is None:
                 self._stop = True
@@ -328,6 +371,8 @@ class DynamicBatcher:
             if in_name in group[0].stable and hasattr(x, "data_ptr"):
                 hint = x.data_ptr()
         inst = self._pick_instance(hint)
+        if self._launch_hist is not None:
+            self._note_launch(inst, total)
         try:
             with _trace.range(f"batch {self.model.name} n={len(group)} b={total} i={inst}"):
                 return self._launch_inner(group, total, inst)
@@ -362,7 +407,8 @@ class DynamicBatcher:
                 dev_inputs = core._to_device(lm, it.inputs, it.stable)
             dev_inputs["__instance__"] = inst
             for ro in it.requested:
-                dest = core._output_destination(lm, ro, out_specs[ro.name], it.batch)
+                dest = (it.dests[ro.name] if it.dests is not None
+                        else core._output_destination(lm, ro, out_specs[ro.name], it.batch))
                 if dest is not None:
                     dev_inputs["__out__" + ro.name] = dest
             x = dev_inputs[in_name]
@@ -423,7 +469,8 @@ class DynamicBatcher:
                 dev_inputs = {}
                 placed = False
                 for ro in it.requested:
-                    dest = core._output_destination(lm, ro, out_specs[ro.name], it.batch)
+                    dest = (it.dests[ro.name] if it.dests is not None
+                        else core._output_destination(lm, ro, out_specs[ro.name], it.batch))
                     if dest is not None:
                         if dest.dtype == out.dtype and dest.is_contiguous():
                             scatter.append((out.data_ptr() + row * out_row_bytes, dest.data_ptr(),

@@ -23,6 +23,7 @@ and back from :class:`InferResponse`.
 from __future__ import annotations
 
 import base64
+import copy
 import json
 import math
 import os
@@ -108,6 +109,18 @@ class InferRequest:
     inputs: List[InputTensor] = field(default_factory=list)
     outputs: Optional[List[RequestedOutput]] = None
     streaming: bool = False
+
+
+class _RequestPlan:
+    """Everything a repeat of one raw request message needs (see ``ServerCore.try_planned``)."""
+
+    __slots__ = ("req", "lm", "inputs", "batch", "stable", "requested", "requested_names", "version", "stats",
+                 "regions", "dests")
+
+    def __init__(self, req, lm, inputs, batch, stable, requested, requested_names, version, stats, regions, dests):
+        self.req, self.lm, self.inputs, self.batch, self.stable = req, lm, inputs, batch, stable
+        self.requested, self.requested_names, self.version, self.stats = requested, requested_names, version, stats
+        self.regions, self.dests = regions, dests
 
 
 @dataclass
@@ -620,6 +633,8 @@ class InferenceCore:
         self.model_control = model_control
         self._lock = threading.RLock()
         self._loaded: Dict[str, LoadedModel] = {}
+        self._plans = {}  # raw request message -> _RequestPlan (see try_planned)
+        self._plan_counts = {"hits": 0, "stored": 0}
         self._failed: Dict[str, str] = {}
         self.sysshm = SystemShmRegistry()
         self.devshm = DeviceShmRegistry()
@@ -884,6 +899,11 @@ class InferenceCore:
                 lines.append(f"# HELP tca_native_{key}_total {text}")
                 lines.append(f"# TYPE tca_native_{key}_total counter")
                 lines.append(f"tca_native_{key}_total {int(counters[key])}")
+        for key, text in (("hits", "Requests queued from the stored plan of their raw message"),
+                          ("stored", "Request plans stored")):
+            lines.append(f"# HELP tca_request_plan_{key}_total {text}")
+            lines.append(f"# TYPE tca_request_plan_{key}_total counter")
+            lines.append(f"tca_request_plan_{key}_total {self._plan_counts[key]}")
         return "\n".join(lines) + "\n"
 
     # ----------------------------------------------------------- trace / log
@@ -1136,6 +1156,7 @@ class InferenceCore:
         if not names:
             return
         leases = req._leases = []
+        req._lease_names = names
         for n in names:
             entry = self.sysshm.acquire(n)
             registry = self.sysshm
@@ -1155,7 +1176,76 @@ class InferenceCore:
             for registry, entry in leases:
                 registry.release(entry)
 
-    def infer(self, req: InferRequest, on_done=None):
+    # ------------------------------------------------------------ request plans
+    # A closed-loop client that keeps its tensors in registered device regions sends the SAME bytes for
+    # every request.  What those bytes mean - the parsed message, the validated tensor views of the
+    # regions, the output destinations - is kept under the raw message as key, so a repeat costs a
+    # dictionary lookup, the region leases and the queue hand-over instead of a parse and a
+    # validation (2-3x less interpreter time per request on the zero-copy path).  A plan is only valid
+    # against the very region entries and the very loaded model it was built for: a re-registered
+    # region or a reloaded model has new objects, and the plan is dropped on the first mismatch.
+    _PLAN_CAPACITY = 4096
+
+    def try_planned(self, key, on_done):
+        """Queue the request whose raw message is ``key`` from its stored plan.  True when it
+        was queued (``on_done`` will be called); False when there is no valid plan (the caller
+        parses the message and calls :meth:`infer` with ``plan_key``)."""
+        plan = self._plans.get(key)
+        if plan is None:
+            return False
+        t_arrive = time.perf_counter_ns()
+        with self._lock:
+            lm = self._loaded.get(plan.req.model_name)
+        leases = []
+        if lm is plan.lm and lm.batcher is not None:
+            for registry, name, entry in plan.regions:
+                got = registry.acquire(name)
+                if got is not entry:
+                    if got is not None:
+                        registry.release(got)
+                    break
+                leases.append((registry, got))
+            else:
+                req = copy.copy(plan.req)
+                req._leases = leases
+                ctx = ExecContext(request_id=req.id, parameters=req.parameters, version=plan.version,
+                                  requested_outputs=plan.requested_names)
+                ctx.stable_inputs = plan.stable
+                lm.batcher.submit_async(req, plan.inputs, plan.batch, plan.stable, plan.requested, ctx, plan.stats,
+                                        t_arrive, plan.version, on_done, dests=plan.dests)
+                self._plan_counts["hits"] += 1
+                return True
+        for registry, entry in leases:
+            registry.release(entry)
+        self._plans.pop(key, None)
+        return False
+
+    def _store_plan(self, key, lm, req, inputs, batch, stable, requested, version, stats):
+        """Keep the plan of a request that is about to be queued, if every repeat of it would be
+        handled the same way: a batched GPU model without fault-injection parameters, no request
+        parameters, every input a zero-copy view of a registered device region."""
+        model = lm.model
+        if (model.parameters or req.parameters or req.streaming or model.sequence or model.decoupled
+                or not req.inputs or any(t.shm is None or t.name not in stable for t in req.inputs)):
+            return
+        leases, names = getattr(req, "_leases", None), getattr(req, "_lease_names", None)
+        if not leases or not names or len(leases) != len(names):
+            return
+        try:
+            dests = {ro.name: self._output_destination(lm, ro, lm.out_specs[ro.name], batch) for ro in requested}
+        except ServerError:
+            return  # the launch reports it
+        if len(self._plans) >= self._PLAN_CAPACITY:
+            self._plans.clear()
+        template = copy.copy(req)
+        template._leases = None
+        self._plan_counts["stored"] += 1
+        self._plans[key] = _RequestPlan(template, lm, inputs, batch, stable, list(requested),
+                                        [r.name for r in requested], version, stats,
+                                        [(registry, name, entry) for name, (registry, entry) in zip(names, leases)],
+                                        dests)
+
+    def infer(self, req: InferRequest, on_done=None, plan_key=None):
         """Run one request.  Returns an :class:`InferResponse` for ordinary
         models, or an iterator of them for decoupled models.
 
@@ -1193,6 +1283,8 @@ class InferenceCore:
             if model.device == "gpu":
                 if lm.batcher is not None:
                     if on_done is not None:
+                        if plan_key is not None:
+                            self._store_plan(plan_key, lm, req, inputs, batch, stable, requested, version, stats)
                         handed_over = True  # released by the batcher when the answer is complete
                         lm.batcher.submit_async(req, inputs, batch, stable, requested, ctx, stats, t_arrive, version,
                                                 on_done)

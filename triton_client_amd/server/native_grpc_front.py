@@ -68,6 +68,8 @@ class NativeGrpcFront:
         self._pool = futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="tca-ngrpc")
         self._streams = {}
         self._streams_lock = threading.Lock()
+        # stored plans for repeated request messages (TCA_REQUEST_PLANS=0: parse and validate every request)
+        self._plans = os.environ.get("TCA_REQUEST_PLANS", "1") != "0"
         self._methods = {}
         svc = pb.DESCRIPTOR.services_by_name["GRPCInferenceService"]
         for m in svc.methods:
@@ -112,6 +114,8 @@ class NativeGrpcFront:
     # ------------------------------------------------------------------ unary
     def _on_unary(self, call, method, data, blob=None, spans=None):
         if method == "ModelInfer":
+            if blob is None and self._plans and self.core.try_planned(data, self._done_callback(call)):
+                return  # a repeat of a message seen before: queued from its stored plan
             try:
                 raw = None
                 if blob is not None:
@@ -127,7 +131,8 @@ class NativeGrpcFront:
                 self._front.finish(call, _INVALID_ARGUMENT, f"malformed ModelInferRequest: {e}")
                 return
             if self.core.uses_batcher(req.model_name) or self.core.runs_inline(req.model_name):
-                self._infer(call, req)  # queues and returns / answers within microseconds
+                # queues and returns / answers within microseconds
+                self._infer(call, req, data if blob is None and self._plans else None)
             else:
                 self._pool.submit(self._infer, call, req)
             return
@@ -149,7 +154,7 @@ class NativeGrpcFront:
         except Exception as e:
             self._front.finish(call, _INTERNAL, f"internal error: {type(e).__name__}: {e}")
 
-    def _infer(self, call, req):
+    def _done_callback(self, call):
         def done(resp, err):
             if err is not None:
                 self._front.finish(call, _STATUS.get(getattr(err, "code", 500), _INTERNAL),
@@ -157,8 +162,12 @@ class NativeGrpcFront:
             else:
                 self._front.reply(call, response_to_proto(resp).SerializeToString())
 
+        return done
+
+    def _infer(self, call, req, plan_key=None):
+        done = self._done_callback(call)
         try:
-            result = self.core.infer(req, on_done=done)
+            result = self.core.infer(req, on_done=done, plan_key=plan_key)
             if result is ASYNC:
                 return
             if not hasattr(result, "outputs"):
