@@ -624,6 +624,14 @@ def test_batched_copy_many_entries_and_alignments(torch):
         assert int(dst[i, n:].sum()) == 0 and int(dst[i, :shift].sum()) == 0
     assert int(dst[150:].sum()) == 0
     batched_copy([])  # no-op
+    # request-sized, 16-byte aligned ranges (whole 16 KiB chunks plus a ragged tail): the gather of a merged batch
+    big_src = torch.randint(0, 255, (16, 1204224 + 48), device="cuda", dtype=torch.uint8, generator=gen)
+    big_dst = torch.zeros(16 * (1204224 + 48) + 64, device="cuda", dtype=torch.uint8)
+    base = (-big_dst.data_ptr()) % 16
+    batched_copy([(big_src[i].data_ptr(), big_dst.data_ptr() + base + i * (1204224 + 48), 1204224 + 40) for i in range(16)])
+    torch.cuda.synchronize()
+    view = big_dst[base: base + 16 * (1204224 + 48)].view(16, -1)
+    assert torch.equal(view[:, :1204224 + 40], big_src[:, :1204224 + 40]) and int(view[:, 1204224 + 40:].sum()) == 0
 
 
 @pytest.mark.gpu
