@@ -170,3 +170,79 @@ def test_busy_region_survives_an_unregister_that_times_out():
 
         shm.destroy_shared_memory_region(region)
         core.shutdown()
+
+
+def test_request_plans_follow_region_and_model_identity():
+    """A stored plan (``InferenceCore.try_planned``) queues a repeat of the same raw message without a parse,
+    holds the region leases for it, and is dropped as soon as a region of that name is another registration
+    or the model has been loaded again.  The batcher is a stub here; the GPU suite runs the real path."""
+    from triton_client_amd.server.core import InferenceCore, InferRequest, InputTensor, RequestedOutput, ShmRef
+
+    core = InferenceCore(models=["custom_identity_int32"])
+    region = _region("/tca_plan_region", 128)
+    submitted = []
+
+    class StubBatcher:
+        def submit_async(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback, dests=None):
+            submitted.append((req, inputs, dests))
+
+        def stop(self):
+            pass
+
+    try:
+        core.sysshm.register("r", region.key, 0, 128)
+        lm = core._get("custom_identity_int32", "")
+        lm.batcher = StubBatcher()
+        req = InferRequest("custom_identity_int32",
+                           inputs=[InputTensor("INPUT0", "INT32", [1, 16], shm=ShmRef("r", 64, 0))],
+                           outputs=[RequestedOutput(name="OUTPUT0", shm=ShmRef("r", 64, 64))])
+        key = b"raw message bytes"
+        assert not core.try_planned(key, lambda resp, err: None)  # nothing stored yet
+        core._lease_regions(req)
+        view = object()
+        core._store_plan(key, lm, req, {"INPUT0": view}, 1, {"INPUT0"}, req.outputs, "1", lm.stats["1"])
+        core.release_request(req)
+        entry = core.sysshm.acquire("r")
+        core.sysshm.release(entry)
+        assert entry.inflight == 0
+        # a repeat: queued with the stored views, one lease per distinct region, its own request object
+        assert core.try_planned(key, lambda resp, err: None)
+        got_req, got_inputs, dests = submitted[-1]
+        assert got_req is not req and got_req.id == req.id and got_inputs["INPUT0"] is view
+        assert set(dests) == {"OUTPUT0"} and entry.inflight == 1
+        core.release_request(got_req)
+        assert entry.inflight == 0
+        core.release_request(got_req)  # idempotent
+        assert entry.inflight == 0
+        # the name comes back as another registration: the plan is not used and is forgotten
+        core.sysshm.unregister("r")
+        core.sysshm.register("r", region.key, 0, 128)
+        n = len(submitted)
+        assert not core.try_planned(key, lambda resp, err: None)
+        assert len(submitted) == n and key not in core._plans
+        probe = core.sysshm.acquire("r")
+        assert probe.inflight == 1  # only this probe's lease: the failed attempt gave its own back
+        core.sysshm.release(probe)
+        # a request with parameters, or with a tensor on the wire, is never stored
+        core._lease_regions(req)
+        core._store_plan(b"k2", lm, InferRequest("custom_identity_int32", parameters={"priority": 1}, inputs=req.inputs),
+                         {"INPUT0": view}, 1, {"INPUT0"}, req.outputs, "1", lm.stats["1"])
+        core._store_plan(b"k3", lm, req, {"INPUT0": view}, 1, set(), req.outputs, "1", lm.stats["1"])
+        assert b"k2" not in core._plans and b"k3" not in core._plans
+        core.release_request(req)
+        core._lease_regions(req)
+        # a reloaded model is another object: its old plans are dropped on first use
+        core._store_plan(key, lm, req, {"INPUT0": view}, 1, {"INPUT0"}, req.outputs, "1", lm.stats["1"])
+        core.release_request(req)
+        assert key in core._plans
+        lm.batcher = None
+        core.load_model("custom_identity_int32")
+        assert not core.try_planned(key, lambda resp, err: None) and key not in core._plans
+        probe = core.sysshm.acquire("r")
+        assert probe.inflight == 1  # every lease of the attempts above was given back
+        core.sysshm.release(probe)
+    finally:
+        import tritonclient.utils.shared_memory as shm
+
+        shm.destroy_shared_memory_region(region)
+        core.shutdown()
