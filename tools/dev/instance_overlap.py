@@ -58,6 +58,23 @@ for label, offset in (("lockstep", False), ("half a forward apart", True), ("loc
     pair = (time.perf_counter() - t0) / iters
     print(f"batch 128, {label}: pair {pair * 1e3:.3f} ms, {2 * b / pair:.0f} img/s", flush=True)
 
+# three instances at once (TCA_RESNET_INSTANCES=3), batches the closed loop could keep full with six in flight
+if m.instance_count >= 3:
+    for b3 in (80, 88, 128):
+        xs3 = [torch.randn(b3, 3, 224, 224, device="cuda").half() for _ in range(3)]
+        outs3 = [torch.empty(b3, 1000, device="cuda") for _ in range(3)]
+        for inst in range(3):
+            for _ in range(3):
+                m.run(xs3[inst], outs3[inst], inst, stable=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            for inst in range(3):
+                m.run(xs3[inst], outs3[inst], inst, stable=True)
+        torch.cuda.synchronize()
+        triple = (time.perf_counter() - t0) / iters
+        print(f"batch {b3} x three instances: {triple * 1e3:.3f} ms per round, {3 * b3 / triple:.0f} img/s", flush=True)
+
 # sustained: the same pair loop for several seconds, throughput per second (clock / power effects of a long run)
 if os.environ.get("TCA_OVERLAP_SUSTAINED", "1") != "0":
     for second in range(6):
