@@ -71,8 +71,8 @@ def parse_args():
                          "'0,0' rehearses three replicas on one GPU)")
     ap.add_argument("--fanout-modes", default="direct,rccl")
     ap.add_argument("--fanout-requests", type=int, default=384)
-    ap.add_argument("--fanout-timeout", type=float, default=300.0,
-                    help="seconds the whole fan-out measurement may take before it is abandoned")
+    ap.add_argument("--fanout-timeout", type=float, default=180.0,
+                    help="seconds the fan-out measurement of ONE transport may take before it is abandoned")
     ap.add_argument("--fanout-child", type=int, default=0, help=argparse.SUPPRESS)  # internal: world size
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=os.environ.get("TCA_BENCH_DIST_BACKEND",
                                                                                        "nccl"),
@@ -517,28 +517,38 @@ def fanout_in_child(args, world):
     import signal
     import subprocess
 
-    cmd = [sys.executable, os.path.abspath(__file__), "--fanout-child", str(world), "--protocol", args.protocol,
-           "--connections", str(args.connections), "--fanout-modes", args.fanout_modes, "--fanout-requests",
-           str(args.fanout_requests), "--batch", str(args.batch)]
-    if args.fanout_devices is not None:
-        cmd += ["--fanout-devices", args.fanout_devices]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
                                                             "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
                                                             "TORCHELASTIC_RUN_ID")}
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
-    try:
-        out, _ = proc.communicate(timeout=args.fanout_timeout)
-    except subprocess.TimeoutExpired:
+    merged = {}
+    # one child per transport, each with its own limit: a transport that hangs costs its own share of the
+    # time and leaves the other one's result alone
+    for mode in [m for m in args.fanout_modes.split(",") if m]:
+        cmd = [sys.executable, os.path.abspath(__file__), "--fanout-child", str(world), "--protocol", args.protocol,
+               "--connections", str(args.connections), "--fanout-modes", mode, "--fanout-requests",
+               str(args.fanout_requests), "--batch", str(args.batch)]
+        if args.fanout_devices is not None:
+            cmd += ["--fanout-devices", args.fanout_devices]
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+        result = None
         try:
-            os.killpg(proc.pid, signal.SIGKILL)  # the child, its server and the replica processes
-        except ProcessLookupError:
-            pass
-        proc.wait()
-        return {"error": f"abandoned after {args.fanout_timeout:.0f} s"}
-    for line in reversed(out.splitlines()):
-        if line.startswith("{"):
-            return json.loads(line)
-    return {"error": f"fan-out process ended with code {proc.returncode} and no result"}
+            out, _ = proc.communicate(timeout=args.fanout_timeout)
+            for line in reversed(out.splitlines()):
+                if line.startswith("{"):
+                    result = json.loads(line)
+                    break
+            if result is None:
+                result = {mode: {"error": f"fan-out process ended with code {proc.returncode} and no result"}}
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)  # the child, its server and the replica processes
+            except ProcessLookupError:
+                pass
+            proc.wait()
+            result = {mode: {"error": f"abandoned after {args.fanout_timeout:.0f} s"}}
+        for key, value in result.items():
+            merged.setdefault(key, value)
+    return merged
 
 
 def launch_ranks(args):
