@@ -11,11 +11,14 @@ def test_table_is_well_formed():
     assert table["conv"], "the shipped table has entries"
     for key, variant in table["conv"].items():
         k, stride, h, w, cin, cout, res, batch = (int(v) for v in key.split(","))
-        assert variant in conv.VARIANTS and variant != "auto"
+        variant, _, staging = variant.partition("/")  # "tile" or "tile/lds2|lds3"
+        assert variant in conv.VARIANTS and variant != "auto" and staging in ("", "lds2", "lds3")
         assert k in (1, 3) and stride in (1, 2) and res in (0, 1) and batch % 8 == 0 and 8 <= batch <= 128
         assert cin % 64 == 0 and cout % 64 == 0 and h == w
         if "x128" in variant:
             assert cout % 128 == 0
+        if "x256" in variant:
+            assert cout % 256 == 0
     for key, mode in table["fused"].items():
         h, w, cin, mid, cout, stride, n3, batch = (int(v) for v in key.split(","))
         assert mode in ("none", "64", "128") and mid in (64, 128) and n3 in (0, 64, 128)

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--streams", type=int, default=1,
                     help="time every candidate on this many streams at once (2: the server's two execution instances)")
+    ap.add_argument("--stagings", action="store_true", help="also try every tile with two and with three LDS stages (measured: the table it gives was "
+                                                          "1.5 %% slower under the headline load than the one without)")
     ap.add_argument("--wide", action="store_true", help="also try the 256-wide and 16-wavefront tiles")
     args = ap.parse_args()
     variants = VARIANTS + (WIDE_VARIANTS if args.wide else ())
@@ -120,6 +122,12 @@ def main():
                     continue  # halo rows + two weight stages do not fit the CU's LDS
                 times[variant] = graph_time(lambda v=variant: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride,
                                                                           padding=pad, variant=v, out=out))
+                if args.stagings and variant not in HALO_VARIANTS:
+                    # the number of LDS stages pinned (the kernel's rule picks it from the grid size)
+                    for staging in ("lds2", "lds3"):
+                        times[f"{variant}/{staging}"] = graph_time(
+                            lambda v=variant, sg=staging: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride, padding=pad,
+                                                                      variant=v, out=out, staging=sg))
             auto = graph_time(lambda: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride, padding=pad,
                                                   variant=0, out=out, tuned=False))
             best = min(times, key=times.get)

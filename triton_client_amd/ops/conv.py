@@ -125,6 +125,10 @@ def _launch(x, weight, bias, residual, out, n, h, w, r, stride, padding, cin, co
     if tuned and variant in (0, "auto"):
         # a measured winner for exactly this layer and batch beats the kernel's threshold rule
         variant = tuning_table()["conv"].get(f"{r},{stride},{h},{w},{cin},{cout},{int(residual is not None)},{n}", 0)
+    if isinstance(variant, str) and "/" in variant:
+        # "tile/staging" (a table entry that also pins the number of LDS stages); an explicit argument wins
+        variant, tuned_staging = variant.split("/", 1)
+        staging = staging or tuned_staging
     code = _variant_code(variant, staging)
     splits = (0 if SPLIT_K else 1) if split_k is None else int(split_k)
     if splits == 1:
