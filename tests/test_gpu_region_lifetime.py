@@ -210,3 +210,39 @@ def test_repeated_messages_run_from_their_plan_on_fresh_contents(served):
         c.unregister_cuda_shared_memory("plan_out0")
         for h in (hin, hout, hin2, hout2):
             hipshm.destroy_shared_memory_region(h)
+
+
+def test_repeated_rest_bodies_run_from_their_plan(served):
+    """The REST front keeps plans too (small JSON bodies whose tensors are region references)."""
+    import tritonclient.http as h
+    import tritonclient.utils.cuda_shared_memory as hipshm
+
+    rng = np.random.default_rng(11)
+    x1 = rng.standard_normal((B, 3, 224, 224)).astype(np.float16)
+    x2 = rng.standard_normal((B, 3, 224, 224)).astype(np.float16)
+    with h.InferenceServerClient(served.http_url) as c:
+        hin = hipshm.create_shared_memory_region("rest_plan_in", IN_BYTES, 0)
+        hout = hipshm.create_shared_memory_region("rest_plan_out", OUT_BYTES, 0)
+        c.register_cuda_shared_memory("rest_plan_in", hipshm.get_raw_handle(hin), 0, IN_BYTES)
+        c.register_cuda_shared_memory("rest_plan_out", hipshm.get_raw_handle(hout), 0, OUT_BYTES)
+        inp = h.InferInput("input", [B, 3, 224, 224], "FP16")
+        inp.set_shared_memory("rest_plan_in", IN_BYTES)
+        out = h.InferRequestedOutput("output")
+        out.set_shared_memory("rest_plan_out", OUT_BYTES)
+        wire = h.InferInput("input", [B, 3, 224, 224], "FP16")
+        before = _plan_counters(served)
+        for x in (x1, x2, x1):
+            wire.set_data_from_numpy(x)
+            ref = c.infer("resnet50", [wire]).as_numpy("output")  # tensors in the body: never planned
+            hipshm.set_shared_memory_region(hin, [x])
+            result = c.infer("resnet50", [inp], outputs=[out])
+            assert result.get_output("output")["parameters"]["shared_memory_region"] == "rest_plan_out"
+            got = hipshm.get_contents_as_numpy(hout, np.float32, [B, 1000])
+            np.testing.assert_allclose(got, ref, rtol=1e-2, atol=1e-2)
+        after = _plan_counters(served)
+        assert after["tca_request_plan_stored_total"] == before["tca_request_plan_stored_total"] + 1
+        assert after["tca_request_plan_hits_total"] == before["tca_request_plan_hits_total"] + 2
+        c.unregister_cuda_shared_memory("rest_plan_in")
+        c.unregister_cuda_shared_memory("rest_plan_out")
+        hipshm.destroy_shared_memory_region(hin)
+        hipshm.destroy_shared_memory_region(hout)

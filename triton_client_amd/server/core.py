@@ -1186,10 +1186,11 @@ class InferenceCore:
     # region or a reloaded model has new objects, and the plan is dropped on the first mismatch.
     _PLAN_CAPACITY = 4096
 
-    def try_planned(self, key, on_done):
+    def try_planned(self, key, on_done=None, on_done_for=None):
         """Queue the request whose raw message is ``key`` from its stored plan.  True when it
-        was queued (``on_done`` will be called); False when there is no valid plan (the caller
-        parses the message and calls :meth:`infer` with ``plan_key``)."""
+        was queued (``on_done``, or ``on_done_for(request)`` for a front whose answer depends on
+        the request, will be called); False when there is no valid plan (the caller parses the
+        message and calls :meth:`infer` with ``plan_key``)."""
         plan = self._plans.get(key)
         if plan is None:
             return False
@@ -1211,6 +1212,8 @@ class InferenceCore:
                 ctx = ExecContext(request_id=req.id, parameters=req.parameters, version=plan.version,
                                   requested_outputs=plan.requested_names)
                 ctx.stable_inputs = plan.stable
+                if on_done is None:
+                    on_done = on_done_for(req)
                 lm.batcher.submit_async(req, plan.inputs, plan.batch, plan.stable, plan.requested, ctx, plan.stats,
                                         t_arrive, plan.version, on_done, dests=plan.dests)
                 self._plan_counts["hits"] += 1

@@ -17,6 +17,7 @@ in the C++ buffer and are aliased by the tensors, not copied.
 
 from __future__ import annotations
 
+import os
 from concurrent import futures
 
 from .core import ASYNC, ServerError
@@ -32,6 +33,8 @@ class NativeHttpFront:
         self.host = host
         self.port = port
         self._pool = futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="tca-nhttp")
+        # stored plans for repeated request bodies (TCA_REQUEST_PLANS=0: parse and validate every request)
+        self._plans = os.environ.get("TCA_REQUEST_PLANS", "1") != "0"
         kwargs = {}
         if tls:  # (certificate chain, private key, client CA or None) as PEM file paths
             kwargs = {"tls_cert": tls[0], "tls_key": tls[1], "tls_client_ca": tls[2]}
@@ -64,9 +67,17 @@ class NativeHttpFront:
             kind = routed[0]
             if kind == "infer":
                 _, model, version, body = routed
+                plan_key = None
+                if (self._plans and len(body) <= 4096 and "inference-header-content-length" not in headers
+                        and "content-encoding" not in headers):
+                    # a small, plain JSON body (tensors by reference): a repeat is queued from its stored plan
+                    plan_key = (model, version, bytes(body))
+                    if self.core.try_planned(plan_key, on_done_for=lambda req: self._done_callback(call, req, headers)):
+                        return
                 req = self.router.parse_infer(model, version, headers, body)
                 if self.core.uses_batcher(model) or self.core.runs_inline(model):
-                    self._infer(call, req, headers)  # queues and returns / answers within microseconds
+                    # queues and returns / answers within microseconds
+                    self._infer(call, req, headers, plan_key)
                 else:
                     self._pool.submit(self._infer, call, req, headers)
             elif kind == "blocking":
@@ -83,7 +94,7 @@ class NativeHttpFront:
         except Exception as e:  # noqa: BLE001
             self._fail(call, e)
 
-    def _infer(self, call, req, headers):
+    def _done_callback(self, call, req, headers):
         def done(resp, err):
             if err is not None:
                 self._fail(call, err if isinstance(err, Exception) else ServerError(str(err), 500))
@@ -94,8 +105,12 @@ class NativeHttpFront:
             except Exception as e:  # noqa: BLE001
                 self._fail(call, e)
 
+        return done
+
+    def _infer(self, call, req, headers, plan_key=None):
+        done = self._done_callback(call, req, headers)
         try:
-            result = self.core.infer(req, on_done=done)
+            result = self.core.infer(req, on_done=done, plan_key=plan_key)
             if result is not ASYNC:
                 done(result, None)
         except Exception as e:  # noqa: BLE001
