@@ -407,7 +407,8 @@ def test_conv3x3_sixteen_wave_tiles_exact(torch):
             assert torch.equal(got.float(), ref), (variant, staging)
 
 
-@pytest.mark.parametrize("shape", [(3, 128, 14, 14, 256), (2, 256, 14, 14, 256), (1, 64, 28, 28, 128), (5, 64, 7, 7, 256)])
+@pytest.mark.parametrize("shape", [(3, 128, 14, 14, 256), (2, 256, 14, 14, 256), (1, 64, 28, 28, 128),
+                                   (5, 64, 7, 7, 256)])
 def test_conv3x3_plain_halo_form_exact(torch, shape):
     """Halo form of the plain 3x3 convolution (input rows in LDS once, the K loop streams weights): integer data,
     image borders inside a tile (several images per tile), ragged last tile, one to four 64-channel slices."""
@@ -420,7 +421,8 @@ def test_conv3x3_plain_halo_form_exact(torch, shape):
     wt[cout - 3, cin - 5, 2, 0] = 3.0
     bias = torch.arange(cout, device="cuda").half()
     res = _nhwc(torch.randint(-4, 5, (b, cout, h, w), device="cuda", generator=gen).half())
-    ref = (torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=1, padding=1) + res.float()).clamp_min(0)
+    ref = torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=1, padding=1)
+    ref = (ref + res.float()).clamp_min(0)
     for variant in ("128x256halo", "128x128halo"):
         if variant == "128x256halo" and cout % 256:
             continue
@@ -628,7 +630,8 @@ def test_batched_copy_many_entries_and_alignments(torch):
     big_src = torch.randint(0, 255, (16, 1204224 + 48), device="cuda", dtype=torch.uint8, generator=gen)
     big_dst = torch.zeros(16 * (1204224 + 48) + 64, device="cuda", dtype=torch.uint8)
     base = (-big_dst.data_ptr()) % 16
-    batched_copy([(big_src[i].data_ptr(), big_dst.data_ptr() + base + i * (1204224 + 48), 1204224 + 40) for i in range(16)])
+    batched_copy([(big_src[i].data_ptr(), big_dst.data_ptr() + base + i * (1204224 + 48), 1204224 + 40)
+                  for i in range(16)])
     torch.cuda.synchronize()
     view = big_dst[base: base + 16 * (1204224 + 48)].view(16, -1)
     assert torch.equal(view[:, :1204224 + 40], big_src[:, :1204224 + 40]) and int(view[:, 1204224 + 40:].sum()) == 0

@@ -183,7 +183,8 @@ def test_request_plans_follow_region_and_model_identity():
     submitted = []
 
     class StubBatcher:
-        def submit_async(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback, dests=None):
+        def submit_async(self, req, inputs, batch, stable, requested, ctx, stats, t_arrive, version, callback,
+                         dests=None):
             submitted.append((req, inputs, dests))
 
         def stop(self):
@@ -225,8 +226,8 @@ def test_request_plans_follow_region_and_model_identity():
         core.sysshm.release(probe)
         # a request with parameters, or with a tensor on the wire, is never stored
         core._lease_regions(req)
-        core._store_plan(b"k2", lm, InferRequest("custom_identity_int32", parameters={"priority": 1}, inputs=req.inputs),
-                         {"INPUT0": view}, 1, {"INPUT0"}, req.outputs, "1", lm.stats["1"])
+        with_params = InferRequest("custom_identity_int32", parameters={"priority": 1}, inputs=req.inputs)
+        core._store_plan(b"k2", lm, with_params, {"INPUT0": view}, 1, {"INPUT0"}, req.outputs, "1", lm.stats["1"])
         core._store_plan(b"k3", lm, req, {"INPUT0": view}, 1, set(), req.outputs, "1", lm.stats["1"])
         assert b"k2" not in core._plans and b"k3" not in core._plans
         core.release_request(req)

@@ -63,7 +63,8 @@ def main():
             end.synchronize()
         return start.elapsed_time(end) * 1e3 / (5 * args.reps)  # us per call
 
-    print(f"{'batch':>5} {'layer':>26} {'eager':>8} {'lib+ep':>8} " + " ".join(f"{v:>8}" for v in MFMA_VARIANTS) + "  best",
+    print(f"{'batch':>5} {'layer':>26} {'eager':>8} {'lib+ep':>8} " + " ".join(f"{v:>8}" for v in MFMA_VARIANTS)
+          + "  best",
           flush=True)
     totals = {}
     for b in [int(v) for v in args.batches.split(",")]:

@@ -11,7 +11,8 @@ import torch
 
 from triton_client_amd.models import MODEL_ZOO
 
-pre = int(os.environ.get("TCA_EXTRA_STREAMS", "0"))  # streams created first: shifts the stream -> hardware queue mapping
+# streams created first: shifts the stream -> hardware queue mapping
+pre = int(os.environ.get("TCA_EXTRA_STREAMS", "0"))
 extra = [torch.cuda.Stream() for _ in range(pre)]
 m = MODEL_ZOO["resnet50"]()
 m.load(0)
@@ -47,7 +48,7 @@ for inst in range(2):
         m.run(xs[inst], outs[inst], inst, stable=True)
 m.run(xh, oh, 1, stable=True)
 torch.cuda.synchronize()
-for label, offset in (("lockstep", False), ("half a forward apart", True), ("lockstep", False), ("half a forward apart", True)):
+for label, offset in (("lockstep", False), ("half a forward apart", True)) * 2:
     t0 = time.perf_counter()
     if offset:
         m.run(xh, oh, 1, stable=True)

@@ -35,8 +35,9 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--streams", type=int, default=1,
                     help="time every candidate on this many streams at once (2: the server's two execution instances)")
-    ap.add_argument("--stagings", action="store_true", help="also try every tile with two and with three LDS stages (measured: the table it gives was "
-                                                          "1.5 %% slower under the headline load than the one without)")
+    ap.add_argument("--stagings", action="store_true",
+                    help="also try every tile with two and with three LDS stages (measured: the table it gives was "
+                         "1.5 %% slower under the headline load than the one without)")
     ap.add_argument("--wide", action="store_true", help="also try the 256-wide and 16-wavefront tiles")
     args = ap.parse_args()
     variants = VARIANTS + (WIDE_VARIANTS if args.wide else ())

@@ -638,6 +638,7 @@ class InferenceCore:
         self._failed: Dict[str, str] = {}
         self.sysshm = SystemShmRegistry()
         self.devshm = DeviceShmRegistry()
+        self.devshm.on_close.append(self._drop_plans_of_region)
         self.native = None  # NativeExecutor once attach_native() has run
         self.trace_global = {
             "trace_file": [""], "trace_level": ["OFF"], "trace_rate": ["1000"], "trace_count": ["-1"],
@@ -1222,6 +1223,16 @@ class InferenceCore:
             registry.release(entry)
         self._plans.pop(key, None)
         return False
+
+    def _drop_plans_of_region(self, base, nbytes):
+        """``DeviceShmRegistry.on_close`` hook: forget the plans whose views alias a mapping that is being closed
+        (they would be refused on their next use anyway; this only keeps dead views from piling up)."""
+        for key, plan in list(self._plans.items()):
+            for _, _, entry in plan.regions:
+                mapping = getattr(entry, "mapping", None)
+                if mapping is not None and mapping.address == base:
+                    self._plans.pop(key, None)
+                    break
 
     def _store_plan(self, key, lm, req, inputs, batch, stable, requested, version, stats):
         """Keep the plan of a request that is about to be queued, if every repeat of it would be
