@@ -127,8 +127,8 @@ def main():
                     # the number of LDS stages pinned (the kernel's rule picks it from the grid size)
                     for staging in ("lds2", "lds3"):
                         times[f"{variant}/{staging}"] = graph_time(
-                            lambda v=variant, sg=staging: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride, padding=pad,
-                                                                      variant=v, out=out, staging=sg))
+                            lambda v=variant, sg=staging: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride,
+                                                                      padding=pad, variant=v, out=out, staging=sg))
             auto = graph_time(lambda: conv.conv2d(x, wt, bias, res, relu=relu, stride=stride, padding=pad,
                                                   variant=0, out=out, tuned=False))
             best = min(times, key=times.get)
