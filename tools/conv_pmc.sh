@@ -12,6 +12,7 @@ PASS1="SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INS
 PASS2="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY"
 n=0
 for layer in "--hw 14 --cin 256 --cout 256 --ksize 3 --variant 128x128w8" "--hw 14 --cin 1024 --cout 256 --ksize 1 --variant 128x128w8" \
+             "--hw 14 --cin 256 --cout 256 --ksize 3 --variant 256x256w16" "--hw 14 --cin 1024 --cout 256 --ksize 1 --variant 256x256w16" \
              "--hw 56 --cin 64 --cout 256 --ksize 1 --variant 128x128w8" "--hw 14 --cin 256 --cout 256 --ksize 3 --variant 128x64" \
              "--hw 56 --cin 64 --cout 64 --ksize 3 --expand 256 --next 64" "--hw 28 --cin 128 --cout 128 --ksize 3 --expand 512"; do
   for pass in "$PASS1" "$PASS2"; do
@@ -35,7 +36,9 @@ for d in sorted(glob.glob(sys.argv[1] + "/cpmc*/")):
             if "ConvGemm" not in name:
                 continue
             m = re.search(r"ConvGemmKernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)", name)
-            short = (f"ConvGemm<{m.group(1)},{m.group(2)},waves={2 * int(m.group(3))},spatial={m.group(4)},glds={m.group(5)},"
+            wm = re.search(r"ELb\dELi(\d+)EE", name)  # wave rows: the last template argument
+            rows = int(wm.group(1)) if wm else 2
+            short = (f"ConvGemm<{m.group(1)},{m.group(2)},waves={rows * int(m.group(3))},spatial={m.group(4)},glds={m.group(5)},"
                      f"fused={m.group(6)},next={m.group(7)}>" if m else name[:60])
             k = (short, r.get("Counter_Name", "?"))
             agg[k][0] += float(r.get("Counter_Value", 0)); agg[k][1] += 1
