@@ -30,7 +30,7 @@ def main(argv=None):
     ap.add_argument("--http-reactors", type=int, default=None,
                     help="epoll threads of the native HTTP front (default 2)")
     ap.add_argument("--grpc-reactors", type=int, default=None,
-                    help="epoll threads of the native gRPC front (default 2)")
+                    help="epoll threads of the native gRPC front (default 4)")
     ap.add_argument("--tls-cert", default=None, help="PEM certificate chain: serve HTTPS / gRPC over TLS")
     ap.add_argument("--tls-key", default=None, help="PEM private key of --tls-cert")
     ap.add_argument("--tls-client-ca", default=None, help="PEM CA bundle: require client certificates signed by it")
