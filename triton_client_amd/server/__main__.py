@@ -28,7 +28,7 @@ def main(argv=None):
     ap.add_argument("--http-impl", choices=["native", "asyncio"], default=None,
                     help="HTTP front: C++ reactors (default) or the pure-Python asyncio one")
     ap.add_argument("--http-reactors", type=int, default=None,
-                    help="epoll threads of the native HTTP front (default 2)")
+                    help="epoll threads of the native HTTP front (default 4)")
     ap.add_argument("--grpc-reactors", type=int, default=None,
                     help="epoll threads of the native gRPC front (default 4)")
     ap.add_argument("--tls-cert", default=None, help="PEM certificate chain: serve HTTPS / gRPC over TLS")
