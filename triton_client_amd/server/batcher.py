@@ -106,8 +106,6 @@ class DynamicBatcher:
         # Execution instances of the model (own HIP stream + own captured graphs each):
         # batches are spread over them and run side by side on the GPU.
         self.instances = int(getattr(self.model, "instance_count", 1)) if hasattr(self.model, "stream_of") else 1
-        # ... and the fill window applies from this many batches enqueued over all instances
-        self.fill_min_inflight = int(os.environ.get("TCA_FILL_MIN_INFLIGHT", self.instances))
         self._busy = [0] * self.instances  # batches enqueued per instance (batcher adds, completers subtract)
         self.split_min_batch = int(os.environ.get("TCA_SPLIT_MIN_BATCH", getattr(self.model, "split_min_batch", 16)))
         self._busy_lock = threading.Lock()
@@ -275,8 +273,7 @@ class DynamicBatcher:
                     # part of a burst, or the first requests coming back after a batch of
                     # several was answered: more is about to arrive
                     deadline = max(deadline, t_first + self.burst_window_s)
-                filling = (self.fill_window_s > 0 and min(self._busy) >= 1
-                           and sum(self._busy) >= self.fill_min_inflight)
+                filling = self.fill_window_s > 0 and min(self._busy) >= 1
                 # every instance still has a batch to run: nothing idles while this one fills up; looked at
                 # again every 200 us, so an instance that runs out of work gets this batch at once
                 remaining = (max(deadline, t_first + self.fill_window_s) if filling else deadline) - time.perf_counter()
