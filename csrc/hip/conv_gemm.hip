@@ -1043,18 +1043,27 @@ constexpr int kStemConv = 2 * kStemPool + 1;       // 17 convolution rows / colu
 constexpr int kStemPixels = kStemConv * kStemConv; // 289
 constexpr int kStemGroups = (kStemPixels + 15) / 16;  // 19 groups of 16 pixels
 constexpr int kStemPatch = 2 * (kStemConv - 1) + 7;   // 39 input rows / columns
-constexpr int kStemPatchPitch = 40;                // halfs per patch row (column 39 is the kw padding)
+constexpr int kStemPatchCols = 40;                 // halfs per patch row that hold pixels (column 39 is the kw padding)
+// The patch is kept TWICE in LDS, the second copy shifted left by two pixels: the 8 input pixels a lane
+// feeds start at column 2 * cx, so in copy (cx & 1) they start at a multiple of 4 halfs and are two aligned
+// 8-byte reads (ds_read_b64: 2 LDS cycles each) instead of four 4-byte ones (ds_read2_b32: 8 cycles per pair).
+// Rows are 128 bytes and the copies 64 bytes (mod 256) apart: the four 16-lane sets of a half-wave - even and
+// odd columns of two consecutive K chunks, i.e. two consecutive patch rows - fall on four disjoint groups of
+// 16 banks.
+constexpr int kStemPatchPitch = 64;                // halfs per patch row in LDS
 constexpr int kStemPatchHalfs = 3 * kStemPatch * kStemPatchPitch;
+constexpr int kStemCopyHalfs = kStemPatchHalfs + 96;  // copy 1 starts here; the 16 zero halfs of the K padding sit between
+static_assert((kStemCopyHalfs * 2) % 256 == 64, "the second patch copy must sit 16 banks from the first");
 constexpr int kStemConvPitch = 72;                 // halfs per convolution pixel in LDS (16-byte aligned rows)
 constexpr int kStemK = 192;
 
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void StemConvPoolKernel(const _Float16* __restrict__ x,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void StemConvPoolKernel(const _Float16* __restrict__ x,
                                                                const _Float16* __restrict__ wk,
                                                                const _Float16* __restrict__ bias,
                                                                _Float16* __restrict__ y, int H, int W, int OH, int OW,
                                                                int PH, int PW, int tiles_w, int tiles_per_image,
                                                                int total_tiles, unsigned x_bytes) {
-  __shared__ __attribute__((aligned(16))) _Float16 patch[kStemPatchHalfs + 16];  // + 16 zero halfs for the K padding
+  __shared__ __attribute__((aligned(256))) _Float16 patch[2 * kStemCopyHalfs];  // two copies; zero halfs for the K padding after the first
   __shared__ __attribute__((aligned(16))) _Float16 conv[kStemGroups * 16 * kStemConvPitch];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1081,7 +1090,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
   for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const half4*>(bias + ni * 16 + (lane >> 4) * 4);
   if (tid < 16) patch[kStemPatchHalfs + tid] = static_cast<_Float16>(0);
 
-  constexpr int kRowDwords = kStemPatchPitch / 2;    // 20 aligned dwords per patch row
+  constexpr int kRowDwords = kStemPatchCols / 2;     // 20 aligned dwords per patch row
+  constexpr int kPitchDwords = kStemPatchPitch / 2;  // dwords per patch row in LDS
   constexpr int kRowStep = kThreads / kRowDwords;    // 12 rows per pass of the block
   constexpr int kLoadIters = (3 * kStemPatch + kRowStep - 1) / kRowStep;  // 10 passes cover the 117 rows
 
@@ -1137,7 +1147,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
       for (int it = 0; it < kLoadIters; ++it) {
         const int rc = load_row0 + it * kRowStep;
-        if (rc < 3 * kStemPatch) reinterpret_cast<uint32_t*>(patch)[rc * kRowDwords + load_j] = staged[it];
+        if (rc < 3 * kStemPatch) {
+          uint32_t* row32 = reinterpret_cast<uint32_t*>(patch) + rc * kPitchDwords;
+          row32[load_j] = staged[it];
+          if (load_j > 0) row32[kStemCopyHalfs / 2 + load_j - 1] = staged[it];  // the copy shifted by two pixels
+        }
       }
     }
     __syncthreads();
@@ -1148,23 +1162,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
       const int qc = q < kStemPixels ? q : kStemPixels - 1;  // the last group is ragged: recompute a valid pixel
       const int r = qc / kStemConv;
       const int cx = qc - r * kStemConv;
-      const int pix_off = 2 * r * kStemPatchPitch + 2 * cx;
+      const int pix_off = 2 * r * kStemPatchPitch + 4 * (cx >> 1) + (cx & 1) * kStemCopyHalfs;
       float4v acc[4];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[ni] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 6; ++s) {
         const int off = chunk_off[s] >= 0 ? chunk_off[s] + pix_off : kStemPatchHalfs;
-        // 8 consecutive input pixels starting at an even half index, i.e. 4-byte aligned
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(patch + off);
+        // 8 consecutive input pixels starting at a multiple of 4 halfs in the lane's copy: two 8-byte reads
+        // (volatile: kept as two ds_read_b64, never merged into one slower ds_read2_b64)
+        using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+        using lds_u2_ptr = const volatile __attribute__((address_space(3))) u32x2*;
+        lds_u2_ptr src = reinterpret_cast<lds_u2_ptr>(reinterpret_cast<uintptr_t>(patch + off));
         union {
-          uint32_t u[4];
+          u32x2 u[2];
           half8 h;
         } frag;
         frag.u[0] = src[0];
         frag.u[1] = src[1];
-        frag.u[2] = src[2];
-        frag.u[3] = src[3];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni][s], frag.h, acc[ni], 0, 0, 0);
@@ -1606,9 +1621,9 @@ int tca_stem_conv_pool_launch(const void* x, const void* wk, const void* bias, v
   const int tiles_h = (ph + kStemPool - 1) / kStemPool, tiles_w = (pw + kStemPool - 1) / kStemPool;
   const long long tiles = static_cast<long long>(batch) * tiles_h * tiles_w;
   if (tiles > 0x7FFFFFFF) return -2;
-  // persistent blocks: three per CU (the LDS limit), each walks tiles with a grid stride and
-  // keeps the weight fragments in registers throughout
-  const long long blocks = tiles < 256 * 3 ? tiles : 256 * 3;
+  // persistent blocks: two per CU (the LDS limit: two patch copies + the convolution tile = 72 KiB), each walks
+  // tiles with a grid stride and keeps the weight fragments in registers throughout
+  const long long blocks = tiles < 256 * 2 ? tiles : 256 * 2;
   hipLaunchKernelGGL(StemConvPoolKernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream), static_cast<const _Float16*>(x),
                      static_cast<const _Float16*>(wk), static_cast<const _Float16*>(bias), static_cast<_Float16*>(y),
