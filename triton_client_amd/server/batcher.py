@@ -266,7 +266,7 @@ class DynamicBatcher:
         deadline = t_first + self.delay_s
         have_slot = False
         cap = self.max_batch
-        if self._adaptive_cap:
+        if self._adaptive_cap and first.stable:  # tensors already on the GPU: a smaller batch costs no extra staging
             seen = self._images_on_gpu + (self.q.qsize() + 1) * first.batch
             self._outstanding_peak = max(seen, self._outstanding_peak * 0.98)
             if self._outstanding_peak <= 0.6 * 4 * self.max_batch:  # clearly fewer than four full batches around
