@@ -512,7 +512,8 @@ class DynamicBatcher:
             batched_copy(scatter, stream)
         event = torch.cuda.Event()
         event.record(stream)
-        self._images_on_gpu += total  # (unlocked: an estimate for the adaptive cap only)
+        with self._busy_lock:
+            self._images_on_gpu += total
         self.completions[inst].put((event, pending, total, t_exec, time.perf_counter_ns()))
 
     def _stage_wire(self, items, sbuf, stream, inst):
@@ -578,7 +579,8 @@ class DynamicBatcher:
             event, pending, total, t_exec, t_enq = entry
             event.synchronize()
             self._instance_done(inst)
-            self._images_on_gpu -= total
+            with self._busy_lock:
+                self._images_on_gpu -= total
             t_done = time.perf_counter_ns()
             self._last_done = (t_done, len(pending))  # closed-loop clients send this many again shortly
             out_specs = {t.name: t for t in self.model.outputs}
