@@ -91,6 +91,13 @@ int tca_conv_pointwise_launch(const void* x, const void* w1, const void* bias1, 
                               const void* residual, void* y, int batch, int in_h, int in_w, int ksize, int stride, int pad,
                               int cin, int mid, int cout, int relu, const void* w3, const void* bias3, void* out3, int n3,
                               int tile_m, const void* xd, void* stream);
+// Bottleneck tail with 64 middle channels organised by rows (bottleneck_rows.hip): 3x3 convolution, 1x1
+// expansion to 256 channels (+ projection shortcut from xd, or residual), ReLU, and the next block's first
+// 1x1 convolution (n3 = 64 or 128 outputs), no workgroup barrier behind the 3x3 part.  w2's first 64 K
+// columns are stored in accumulator order (ops/conv.py: permute_mid_k).
+int tca_bottleneck_rows_launch(const void* x, const void* w1, const void* bias1, const void* w2, const void* bias2,
+                               const void* residual, void* y, int batch, int h, int w, int cout, const void* w3,
+                               const void* bias3, void* out3, int n3, const void* xd, void* stream);
 int tca_conv_gemm_splitk_launch(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                                 int in_h, int in_w, int ksize, int stride, int pad, int cin, int cout, int relu,
                                 int variant, int splits, void* partials, unsigned long long partial_bytes,

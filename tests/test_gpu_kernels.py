@@ -686,3 +686,99 @@ def test_stem_conv_pool_exact_integer_taps(torch):
     ref = torch.nn.functional.conv2d(x.float(), wt.float(), bias.float(), stride=2, padding=3).clamp_min(0)
     ref = torch.nn.functional.max_pool2d(ref, 3, stride=2, padding=1)
     assert torch.equal(got.float(), ref)
+
+
+def _rows_block_operands(torch, b, h, w, n3, proj, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    t = _nhwc(torch.randn(b, 64, h, w, device="cuda", generator=gen).half())
+    w1 = _nhwc((torch.randn(64, 64, 3, 3, device="cuda", generator=gen) / 24.0).half())
+    b1 = torch.randn(64, device="cuda", generator=gen).half()
+    w2 = (torch.randn(256, 64, device="cuda", generator=gen) / 8.0).half()
+    b2 = torch.randn(256, device="cuda", generator=gen).half()
+    w3 = (torch.randn(n3, 256, device="cuda", generator=gen) / 16.0).half()
+    b3 = torch.randn(n3, device="cuda", generator=gen).half()
+    x0 = wd = res = None
+    if proj:
+        x0 = _nhwc(torch.randn(b, 64, h, w, device="cuda", generator=gen).half())
+        wd = (torch.randn(256, 64, device="cuda", generator=gen) / 8.0).half()
+    else:
+        res = _nhwc(torch.randn(b, 256, h, w, device="cuda", generator=gen).half())
+    return t, w1, b1, w2, b2, w3, b3, x0, wd, res
+
+
+@pytest.mark.parametrize("n3,proj", [(64, False), (128, False), (64, True)])
+@pytest.mark.parametrize("shape", [(2, 56, 56), (1, 15, 13), (3, 9, 11), (5, 28, 28), (16, 56, 56)])
+def test_bottleneck_rows_matches_reference(torch, shape, n3, proj):
+    """The row-organised bottleneck kernel (3x3 + expansion (+ projection | residual) + next 1x1, no
+    barrier behind the 3x3 part) against fp32 PyTorch and against the chunked fused kernel."""
+    from triton_client_amd.ops import conv
+
+    b, h, w = shape
+    t, w1, b1, w2, b2, w3, b3, x0, wd, res = _rows_block_operands(torch, b, h, w, n3, proj, 17 * n3 + h + int(proj))
+    F = torch.nn.functional
+    mid = F.conv2d(t.float(), w1.float(), b1.float(), padding=1).clamp_min(0).half().float()
+    ref = F.conv2d(mid, w2.float().reshape(256, 64, 1, 1), b2.float())
+    if proj:
+        ref = ref + F.conv2d(x0.float(), wd.float().reshape(256, 64, 1, 1))
+        wcat = torch.cat([w2, wd], dim=1).contiguous()
+    else:
+        ref = ref + res.float()
+        wcat = w2
+    ref = ref.clamp_min(0)
+    y, nxt = conv.bottleneck_rows(t, w1, b1, conv.permute_mid_k(wcat), b2, res, w3, b3, proj_input=x0)
+    torch.testing.assert_close(y.float(), ref, rtol=5e-3, atol=5e-3)
+    nref = F.conv2d(y.float(), w3.float().reshape(n3, 256, 1, 1), b3.float()).clamp_min(0)
+    torch.testing.assert_close(nxt.float(), nref, rtol=4e-3, atol=4e-3)
+    y_old, nxt_old = conv.conv2d_pointwise(t, w1, b1, wcat, b2, res, relu=True, padding=1, next_weight=w3,
+                                           next_bias=b3, proj_input=x0)
+    torch.testing.assert_close(y.float(), y_old.float(), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(nxt.float(), nxt_old.float(), rtol=4e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("n3,proj", [(64, False), (128, False), (64, True)])
+def test_bottleneck_rows_exact_integers(torch, n3, proj):
+    """Small integers keep every intermediate exact in fp16: a wrong K permutation of the second
+    product, a wrong weight slab, swizzle, tap or phase changes sums.  Weights are asymmetric and
+    sparse, every output channel and pixel is checked, M is not a multiple of the tile."""
+    from triton_client_amd.ops import conv
+
+    F = torch.nn.functional
+    gen = torch.Generator(device="cuda").manual_seed(5 + n3 + int(proj))
+
+    def sparse(shape, p, value=1.0):
+        out = torch.zeros(shape, device="cuda")
+        out[torch.rand(shape, device="cuda", generator=gen) < p] = value
+        return out
+
+    b, h, w = 3, 13, 11  # M = 429: three full tiles and a partial one
+    t = _nhwc(torch.randint(-1, 2, (b, 64, h, w), device="cuda", generator=gen).half())
+    w1 = sparse((64, 64, 3, 3), 0.05)
+    w1[3, 5, 0, 2] = -2.0
+    w1 = _nhwc(w1.half())
+    b1 = torch.randint(-2, 3, (64,), device="cuda", generator=gen).half()
+    w2 = sparse((256, 64), 0.1)
+    w2[7, 63] = -3.0
+    w2[200, 17] = 2.0
+    b2 = torch.randint(-2, 3, (256,), device="cuda", generator=gen).half()
+    w3 = sparse((n3, 256), 0.03)
+    w3[n3 - 1, 255] = -1.0
+    b3 = torch.randint(-2, 3, (n3,), device="cuda", generator=gen).half()
+    mid = F.conv2d(t.float(), w1.float(), b1.float(), padding=1).clamp_min(0)
+    ref = F.conv2d(mid, w2.reshape(256, 64, 1, 1), b2.float())
+    x0 = res = None
+    wcat = w2.half()
+    if proj:
+        x0 = _nhwc(torch.randint(-1, 2, (b, 64, h, w), device="cuda", generator=gen).half())
+        wd = sparse((256, 64), 0.1)
+        wd[100, 1] = -2.0
+        ref = ref + F.conv2d(x0.float(), wd.reshape(256, 64, 1, 1))
+        wcat = torch.cat([w2, wd], dim=1).half().contiguous()
+    else:
+        res = _nhwc(torch.randint(-3, 4, (b, 256, h, w), device="cuda", generator=gen).half())
+        ref = ref + res.float()
+    ref = ref.clamp_min(0)
+    nref = F.conv2d(ref, w3.reshape(n3, 256, 1, 1), b3.float()).clamp_min(0)
+    assert mid.abs().max() < 2048 and ref.abs().max() < 2048 and nref.abs().max() < 2048  # exactly representable
+    y, nxt = conv.bottleneck_rows(t, w1, b1, conv.permute_mid_k(wcat), b2, res, w3.half(), b3, proj_input=x0)
+    assert torch.equal(y.float(), ref)
+    assert torch.equal(nxt.float(), nref)

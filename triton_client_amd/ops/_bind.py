@@ -126,6 +126,10 @@ def install(lib):
                                               c_int,
                                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.tca_bottleneck_rows_launch.restype = c_int
+    lib.tca_bottleneck_rows_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                               c_void_p, c_void_p]
     lib.tca_conv_gemm_splitk_launch.restype = c_int
     lib.tca_conv_gemm_splitk_launch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -297,6 +297,66 @@ def conv2d_pointwise(x, weight, bias, weight2, bias2=None, residual=None, relu=T
     return out if next_weight is None else (out, out3)
 
 
+def permute_mid_k(weight2):
+    """``[Cout, 64 (+ 64)]`` expansion weights with the first 64 K columns reordered to the order in which
+    the row-organised bottleneck kernel holds the middle activation - straight out of the 3x3 product's
+    accumulator registers: position ``32 s + 8 q + j`` takes middle channel ``16 (2 s + j // 4) + 4 q + j % 4``.
+    Columns past 64 (the projection shortcut's) keep their order."""
+    import torch
+
+    order = [16 * (2 * s + j // 4) + 4 * q + j % 4 for s in range(2) for q in range(4) for j in range(8)]
+    index = torch.tensor(order + list(range(64, weight2.shape[1])), device=weight2.device)
+    return weight2.index_select(1, index).contiguous()
+
+
+def bottleneck_rows(x, weight, bias, weight2_permuted, bias2, residual, next_weight, next_bias=None, proj_input=None,
+                    out=None):
+    """``y = relu(conv1x1(relu(conv3x3(x) + bias), W2) (+ conv1x1(proj_input, Wd)) + bias2 (+ residual))`` and
+    ``t = relu(conv1x1(y, next_weight) + next_bias)`` in one kernel whose wavefronts own pixel rows for all
+    channels (``csrc/hip/bottleneck_rows.hip``): no workgroup barrier after the 3x3 part.  Shapes: 64 input and
+    middle channels, 256 output channels, stride 1, padding 1, width <= 62, ``next_weight`` ``[64 | 128, 256]``
+    (64 with ``proj_input``).  ``weight2_permuted`` comes from :func:`permute_mid_k`.  Returns ``(y, t)``."""
+    import torch
+
+    if not _is_nhwc(x) or x.dtype != torch.float16 or x.shape[1] != 64:
+        raise ValueError("x must be a channels-last fp16 [N, 64, H, W] tensor")
+    n, _, h, w = x.shape
+    k2 = 64 + (64 if proj_input is not None else 0)
+    n3 = next_weight.shape[0]
+    if (tuple(weight.shape) != (64, 64, 3, 3) or not weight.is_contiguous(memory_format=torch.channels_last)
+            or weight.dtype != torch.float16):
+        raise ValueError("weight must be a channels-last fp16 [64, 64, 3, 3] tensor")
+    if (tuple(weight2_permuted.shape) != (256, k2) or not weight2_permuted.is_contiguous()
+            or weight2_permuted.dtype != torch.float16):
+        raise ValueError(f"weight2_permuted must be a contiguous fp16 [256, {k2}] matrix")
+    if (n3 not in (64, 128) or tuple(next_weight.shape) != (n3, 256) or not next_weight.is_contiguous()
+            or next_weight.dtype != torch.float16 or (proj_input is not None and n3 != 64)):
+        raise ValueError("next_weight must be a contiguous fp16 [64 | 128, 256] matrix (64 rows with proj_input)")
+    for b, c in ((bias, 64), (bias2, 256), (next_bias, n3)):
+        if b is not None and (b.numel() != c or b.dtype != torch.float16 or not b.is_contiguous()):
+            raise ValueError("biases must be contiguous fp16 vectors of the matching channel count")
+    if bias is None:
+        raise ValueError("the 3x3 convolution's bias is required")
+    if residual is not None and (proj_input is not None or tuple(residual.shape) != (n, 256, h, w)
+                                 or not _is_nhwc(residual) or residual.dtype != torch.float16):
+        raise ValueError("residual must be a channels-last fp16 [N, 256, H, W] tensor (and excludes proj_input)")
+    if proj_input is not None and (tuple(proj_input.shape) != (n, 64, h, w) or not _is_nhwc(proj_input)
+                                   or proj_input.dtype != torch.float16):
+        raise ValueError("proj_input must be a channels-last fp16 [N, 64, H, W] tensor")
+    if out is None:
+        out = torch.empty((n, 256, h, w), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    elif tuple(out.shape) != (n, 256, h, w) or not _is_nhwc(out):
+        raise ValueError("out must be a channels-last tensor of the output shape")
+    out3 = torch.empty((n, n3, h, w), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    rc = lib().tca_bottleneck_rows_launch(
+        x.data_ptr(), weight.data_ptr(), bias.data_ptr(), weight2_permuted.data_ptr(),
+        bias2.data_ptr() if bias2 is not None else None, residual.data_ptr() if residual is not None else None,
+        out.data_ptr(), n, h, w, 256, next_weight.data_ptr(), next_bias.data_ptr() if next_bias is not None else None,
+        out3.data_ptr(), n3, proj_input.data_ptr() if proj_input is not None else None, _stream())
+    check(rc, "tca_bottleneck_rows_launch")
+    return out, out3
+
+
 def bias_act_(y, bias, residual=None, relu=False):
     """In place ``y = act(y + bias (+ residual))`` on a channels-last fp16 tensor."""
     import torch
