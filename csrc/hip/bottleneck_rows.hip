@@ -29,8 +29,8 @@
 // the tile touch are brought into LDS once by LDS-DMA, the K loop streams the nine 8 KiB weight
 // taps through three LDS stages (counted vmcnt, one raw barrier per tap).
 //
-// LDS (80 KiB, two blocks per CU):   K loop:  [0,32K) halo   [32K,56K) weight taps
-//                                    after :  [0,32K) W2     [32K,64K) W3      [64K,80K) wave tiles
+// LDS (72.5 KiB, two blocks per CU): K loop:  [0,32K) halo   [32K,56K) weight taps
+//                                    after :  [0,32K) W2     [32K,64K) W3      [64K,72K) wave tiles, biases
 // Forms whose W2 / W3 exceed 32 KiB (projection shortcut inside: K2 = 128; N3 = 128) run the 256
 // output channels in two phases of 128 and re-fill the weight space in between (two barriers).
 #include <hip/hip_runtime.h>
@@ -95,6 +95,8 @@ struct RowsArgs {
   int H;
   int W;
   int xcd_chunk;
+  int ablate;  // measurements only (TCA_ROWS_ABLATE): 1 = no y stores, 2 = no residual loads, 4 = no out3 stores,
+               // 8 = stop after the 3x3 part, 16 = no MFMAs in the 3x3 part, 32 = none behind it
 };
 
 template <int kN3, int kXS>
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
   _Float16* const w1s = lds + 16384;   // three stages of [64][64]
   _Float16* const w2s = lds;           // [kK2/64][kRows2][64]
   _Float16* const w3s = lds + 16384;   // [kCPP][kN3][64]
-  _Float16* const tiles = lds + 32768;
+  _Float16* const tiles = lds + 32768;        // 8 x [16 pixels][32 channels]
+  _Float16* const b2s = lds + 32768 + 8 * 512;  // the second product's 256 biases
 
   int bid = blockIdx.x;
   if (a.xcd_chunk > 0) bid = (bid & 7) * a.xcd_chunk + (bid >> 3);
@@ -158,12 +161,12 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
   const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w1), 0, 64 * 576 * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w2), 0, kN2 * kK2 * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w3), 0, kN3 * kN2 * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, static_cast<int>(m_bytes * (kN2 * 2u)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t o3_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out3, 0, static_cast<int>(m_bytes * (kN3 * 2u)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (a.ablate & 1) ? 0 : static_cast<int>(m_bytes * (kN2 * 2u)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o3_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out3, 0, (a.ablate & 4) ? 0 : static_cast<int>(m_bytes * (kN3 * 2u)), 0x00020000);
   // a null residual / xd gets an empty descriptor: every load returns zeros
   const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<_Float16*>(a.residual != nullptr ? a.residual : a.x), 0,
-      a.residual != nullptr ? static_cast<int>(m_bytes * (kN2 * 2u)) : 0, 0x00020000);
+      a.residual != nullptr && !(a.ablate & 2) ? static_cast<int>(m_bytes * (kN2 * 2u)) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t xd_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<_Float16*>(kXS > 0 ? a.xd : a.x), 0, kXS > 0 ? static_cast<int>(m_bytes * 128u) : 0, 0x00020000);
 
@@ -201,7 +204,10 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
 #pragma unroll
     for (int i = 0; i < kW3Vecs; ++i) *reinterpret_cast<uint4v*>(w3s + (i * kThreads + tid) * 8) = w3r[i];
   };
-  half8 res[2][2];  // residual rows: [chunk parity][32-channel half]
+  // Residual rows of all four chunks.  EVERY load of this kernel is issued before its first store: the
+  // vector-memory counter retires in order, so a wait for a load issued behind a store would also wait
+  // for that store's acknowledgement - the one round trip the kernel has no need to wait for.
+  half8 res[4][2];  // [chunk][32-channel half]
   auto load_res = [&](int chunk, half8 (&dst)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -214,16 +220,13 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
     for (int s = 0; s < 2; ++s)
       bxd[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xd_rsrc, static_cast<int>(xd_off), s * 64, 0));
   }
-  load_res(0, res[0]);
-  load_res(1, res[1]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) load_res(c, res[c]);
+  uint4v b2v{0u, 0u, 0u, 0u};  // 8 of the second product's biases per thread of the first half-wave, parked in LDS later
+  if (a.bias2 != nullptr && tid < 32) b2v = *reinterpret_cast<const uint4v*>(a.bias2 + tid * 8);
   float4v acc1[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) acc1[f] = Widen(*reinterpret_cast<const half4*>(a.bias1 + f * 16 + q * 4));
-  // biases of the later products: the second product's one chunk ahead of its use
-  half4 b2[4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-    b2[f] = a.bias2 != nullptr ? *reinterpret_cast<const half4*>(a.bias2 + f * 16 + q * 4) : half4{0, 0, 0, 0};
 
   // ---- 3x3 convolution: halo + nine weight taps ------------------------------------------------
   {
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
     const int hr = i_local + kh * W + kw;
     const int x_off = ((taps >> tap) & 1u) ? hr * 64 + (((q ^ hr) & 7) * 8) : zero_off;
     const _Float16* ws = w1s + (tap % 3) * 4096;
+    if (a.ablate & 16) continue;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const half8 xf = *reinterpret_cast<const half8*>(halo + (x_off ^ (kk * 32)));
@@ -278,15 +282,24 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
     const half4 lo = PackRelu(acc1[2 * s], true), hi = PackRelu(acc1[2 * s + 1], true);
     bmid[s] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   }
+  if (a.ablate & 8) {
+    if (bmid[0][0] == static_cast<_Float16>(12345.f)) a.y[tid] = bmid[1][3];  // keeps the K loop alive
+    return;
+  }
   LdsBarrier();  // every wave is done with the halo and the weight taps
   store_weights();
+  if (tid < 32) *reinterpret_cast<uint4v*>(b2s + tid * 8) = b2v;
   if constexpr (kPhases > 1) load_weights(1);
   LdsBarrier();
 
   // ---- second and third product, wave by wave ----------------------------------------------------
-  _Float16* const tile = tiles + wave * 1024;
-  const int tw_off = px * 64 + (q & 1) * 4;   // + ((2 f + q / 2) ^ swz) * 8: channels 16 f + 4 q .. + 3 of pixel px
-  const int tw_chunk = q >> 1;
+  // the wave's transposing tile: [16 pixels][32 channels], 64-byte rows whose 16-byte chunks are XOR-ed with
+  // (pixel / 2) % 4 (pixels two apart share their banks on the write side)
+  _Float16* const tile = tiles + wave * 512;
+  const int tswz = (px >> 1) & 3;
+  const int tw0 = px * 32 + (((q >> 1) ^ tswz) * 8) + (q & 1) * 4;        // channels 4 q .. + 3 of the half
+  const int tw1 = px * 32 + (((2 + (q >> 1)) ^ tswz) * 8) + (q & 1) * 4;  // channels 16 + 4 q .. + 3
+  const int tr = px * 32 + ((q ^ tswz) * 8);                              // channels 8 q .. + 7
   float4v acc3[kNI3];
   half4 b3[kNI3];  // added at the very end: requested here, long there by then
 #pragma unroll
@@ -306,10 +319,7 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
       const int c = ph * kCPP + cc;
       float4v acc2[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        acc2[f] = Widen(b2[f]);
-        if (c + 1 < 4 && a.bias2 != nullptr) b2[f] = *reinterpret_cast<const half4*>(a.bias2 + (c + 1) * 64 + f * 16 + q * 4);
-      }
+      for (int f = 0; f < 4; ++f) acc2[f] = Widen(*reinterpret_cast<const half4*>(b2s + c * 64 + f * 16 + q * 4));
 #pragma unroll
       for (int ks = 0; ks < kK2 / 64; ++ks) {
 #pragma unroll
@@ -319,28 +329,29 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
           for (int f = 0; f < 4; ++f)
             wf[f] = *reinterpret_cast<const half8*>(w2s + (ks * kRows2 + cc * 64 + f * 16) * 64 + (frag_off ^ (s * 32)));
           const half8 b = ks == 0 ? bmid[s] : bxd[s];
+          if (a.ablate & 32) continue;
 #pragma unroll
           for (int f = 0; f < 4; ++f) acc2[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f], b, acc2[f], 0, 0, 0);
         }
       }
-      // transposition through the wave's own tile: no barrier, LDS operations of a wave run in order
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-        *reinterpret_cast<half4*>(tile + tw_off + (((2 * f + tw_chunk) ^ swz) * 8)) = PackRelu(acc2[f], false);
+      // transposition through the wave's own tile, 32 channels at a time: no barrier, LDS operations of a
+      // wave run in order
       half8 out[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        half8 v = *reinterpret_cast<const half8*>(tile + (frag_off ^ (s * 32)));
-        v = v + res[c & 1][s];  // packed fp16 adds (zeros without a residual)
+        *reinterpret_cast<half4*>(tile + tw0) = PackRelu(acc2[2 * s], false);
+        *reinterpret_cast<half4*>(tile + tw1) = PackRelu(acc2[2 * s + 1], false);
+        half8 v = *reinterpret_cast<const half8*>(tile + tr);
+        v = v + res[c][s];  // packed fp16 adds (zeros without a residual)
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] > static_cast<_Float16>(0) ? v[j] : static_cast<_Float16>(0);
         out[s] = v;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), y_rsrc, static_cast<int>(y_off), (c * 64 + s * 32) * 2, 0);
       }
-      if (c + 2 < 4) load_res(c + 2, res[c & 1]);
       // third product: the finished values are its activation operand as they stand
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (a.ablate & 32) break;
 #pragma unroll
         for (int f = 0; f < kNI3; ++f) {
           const half8 wf = *reinterpret_cast<const half8*>(w3s + (cc * kN3 + f * 16) * 64 + (frag_off ^ (s * 32)));
@@ -351,22 +362,17 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
   }
   // third result: ReLU, transposed 64 channels at a time through the wave's tile, 16-byte stores
 #pragma unroll
-  for (int h = 0; h < kN3 / 64; ++h) {
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-      *reinterpret_cast<half4*>(tile + tw_off + (((2 * f + tw_chunk) ^ swz) * 8)) =
-          PackRelu(acc3[h * 4 + f] + Widen(b3[h * 4 + f]), true);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const half8 v = *reinterpret_cast<const half8*>(tile + (frag_off ^ (s * 32)));
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), o3_rsrc, static_cast<int>(o3_off), (h * 64 + s * 32) * 2, 0);
-    }
+  for (int h = 0; h < kN3 / 32; ++h) {
+    *reinterpret_cast<half4*>(tile + tw0) = PackRelu(acc3[2 * h] + Widen(b3[2 * h]), true);
+    *reinterpret_cast<half4*>(tile + tw1) = PackRelu(acc3[2 * h + 1] + Widen(b3[2 * h + 1]), true);
+    const half8 v = *reinterpret_cast<const half8*>(tile + tr);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), o3_rsrc, static_cast<int>(o3_off), h * 64, 0);
   }
 }
 
 template <int kN3, int kXS>
 int LaunchRows(const RowsArgs& args, hipStream_t st) {
-  constexpr size_t kLdsBytes = 80 * 1024;
+  constexpr size_t kLdsBytes = 72 * 1024 + 512;  // weights of a phase, eight 1 KiB tiles, 256 biases
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&BottleneckRowsKernel<kN3, kXS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   if (attr != hipSuccess) return -1000 - static_cast<int>(attr);
@@ -414,6 +420,11 @@ int tca_bottleneck_rows_launch(const void* x, const void* w1, const void* bias1,
   a.H = h;
   a.W = w;
   a.xcd_chunk = 0;
+  static const int ablate = [] {
+    const char* v = std::getenv("TCA_ROWS_ABLATE");
+    return v ? std::atoi(v) : 0;
+  }();
+  a.ablate = ablate;
   auto st = static_cast<hipStream_t>(stream);
   if (xd != nullptr) return LaunchRows<64, 1>(a, st);
   return n3 == 64 ? LaunchRows<64, 0>(a, st) : LaunchRows<128, 0>(a, st);

@@ -66,4 +66,4 @@ for batch in batches:
         mb = batch * h * w * (64 + 256 * (1 if proj else 2) + n3 + (64 if proj else 0)) * 2 / 1e6
         t64, t128, tr = graph_time(chunked(64)), graph_time(chunked(128)), graph_time(rows)
         print(f"batch {batch:3d} n3={n3:3d} proj={int(proj)}: chunked 64-px {t64:7.2f} us, 128-px {t128:7.2f} us, "
-              f"rows {tr:7.2f} us ({mb / tr / 1e6 * 1e6 / 1e6:.2f} TB/s)", flush=True)
+              f"rows {tr:7.2f} us ({mb / tr:.2f} TB/s)", flush=True)

@@ -323,6 +323,7 @@ class ResNet50(Model):
 
         blocks = []
         self._proj = {}  # block index -> ([expansion | projection] weights, summed bias) for the in-kernel shortcut
+        self._rows_w2 = {}  # block index -> permuted expansion (| projection) weights of the row-organised kernel
         for index, blk in enumerate(net.blocks):
             blocks.append((mat(blk.a), spatial(blk.b), mat(blk.c), mat(blk.down) if blk.down is not None else None))
             a, mid, c, down = blocks[-1]
@@ -330,6 +331,12 @@ class ResNet50(Model):
                     and c[2] == 1):
                 self._proj[index] = (torch.cat([c[0], down[0]], dim=1).contiguous(),
                                      (c[1].float() + down[1].float()).half().contiguous())
+            # expansion weights in the K order of the row-organised block kernel (64 -> 64 -> 256, stride 1)
+            w4 = mid[0]
+            if tuple(w4.shape) == (64, 64, 3, 3) and mid[2] == 1 and mid[3] == 1 and c[0].shape[0] == 256 and c[2] == 1:
+                from ..ops import conv as _conv
+
+                self._rows_w2[index] = _conv.permute_mid_k(self._proj[index][0] if index in self._proj else c[0])
         self._plan = (spatial(net.stem), blocks)
         # the stem also as the packed matrix of the fused conv + bias + ReLU + max-pool kernel
         from ..ops import conv
@@ -403,6 +410,14 @@ class ResNet50(Model):
                 main.wait_stream(side)
             attach = self._attach_next(mid, c, nxt)
             w4, bias, stride, pad = mid
+            rows_w2 = self._rows_w2.get(index) if (self.fused_expansion and attach and t.shape[3] <= 62) else None
+            if (rows_w2 is not None and (proj is not None or down is None) and (proj is None or nxt[0].shape[0] == 64)
+                    and conv.tuned_rows(nxt[0].shape[0], proj is not None, t.shape[0])):
+                # stage-1 block on the row-organised kernel: waves own pixel rows, no barrier behind the 3x3 part
+                y, t_ahead = conv.bottleneck_rows(t, w4, bias, rows_w2, proj[1] if proj is not None else c[1],
+                                                  None if proj is not None else identity, nxt[0], nxt[1],
+                                                  proj_input=y if proj is not None else None)
+                continue
             if proj is not None:
                 n3_ok = attach and nxt[0].shape[0] == 64
                 result = conv.conv2d_pointwise(t, w4, bias, proj[0], proj[1], None, relu=True, stride=1, padding=pad,

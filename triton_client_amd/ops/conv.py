@@ -107,6 +107,24 @@ def tuned_block_mode(h, w, cin, mid, cout, stride, n3, batch):
     return tuning_table()["fused"].get(f"{h},{w},{cin},{mid},{cout},{stride},{n3},{batch}")
 
 
+def tuned_rows(n3, proj, batch):
+    """Whether the row-organised bottleneck kernel serves a stage-1 block (``n3`` outputs of the attached next
+    convolution, ``proj`` = projection shortcut inside) at this batch: the measured table (``tools/tune_rows.py``)
+    where it has the batch, else the rule those measurements suggest - with the projection inside always; a
+    residual and 64 next outputs up to batch 64; 128 next outputs up to batch 32."""
+    import os
+
+    forced = os.environ.get("TCA_CONV_ROWS")  # A/B switch: 0 = never, 1 = wherever the kernel applies
+    if forced in ("0", "1"):
+        return forced == "1"
+    hit = tuning_table().get("rows", {}).get(f"{n3},{int(bool(proj))},{batch}")
+    if hit is not None:
+        return bool(hit)
+    if proj:
+        return True
+    return batch <= (64 if n3 == 64 else 32)
+
+
 def _stream():
     import torch
 
