@@ -31,8 +31,10 @@
 //
 // LDS (72.5 KiB, two blocks per CU): K loop:  [0,32K) halo   [32K,56K) weight taps
 //                                    after :  [0,32K) W2     [32K,64K) W3      [64K,72K) wave tiles, biases
-// Forms whose W2 / W3 exceed 32 KiB (projection shortcut inside: K2 = 128; N3 = 128) run the 256
-// output channels in two phases of 128 and re-fill the weight space in between (two barriers).
+// With the projection shortcut inside (K2 = 128) W2 exceeds its 32 KiB: the 256 output channels run in two
+// phases of 128 and the weight space is re-filled in between (two barriers).  With N3 = 128 the third
+// product runs 64 of its outputs at a time: the second 64 rows of W3 replace the first ones behind the
+// chunk loop and are multiplied with the output chunks, which stay in registers for that.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -102,19 +104,21 @@ struct RowsArgs {
 template <int kN3, int kXS>
 __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) {
   constexpr int kK2 = 64 + 64 * kXS;                       // K of the second product
-  constexpr int kPhases = (kXS > 0 || kN3 > 64) ? 2 : 1;   // output-channel phases (weights of one phase fit LDS)
+  constexpr int kPhases = kXS > 0 ? 2 : 1;                 // output-channel phases (the weights of one phase fit LDS)
+  constexpr int kPasses3 = kN3 / 64;                       // the third product runs 64 of its outputs at a time
   constexpr int kCPP = 4 / kPhases;                        // 64-channel chunks per phase
   constexpr int kRows2 = kN2 / kPhases;                    // W2 rows per phase
   constexpr int kW2Vecs = kRows2 * (kK2 / 8) / kThreads;   // 16-byte vectors per thread and phase
-  constexpr int kW3Vecs = kN3 * (kCPP * 8) / kThreads;
-  constexpr int kNI3 = kN3 / 16;
+  constexpr int kW3Vecs = 64 * (kCPP * 8) / kThreads;
+  constexpr int kNI3 = 4;                                  // 16-channel fragments of one pass
   static_assert(kW2Vecs >= 1 && kW3Vecs >= 1, "weight parts must cover the block");
-  static_assert(kRows2 * kK2 <= 16384 && kN3 * kCPP * 64 <= 16384, "a phase's weights exceed their 32 KiB");
+  static_assert(kRows2 * kK2 <= 16384, "a phase's weights exceed their 32 KiB");
+  static_assert(kPasses3 == 1 || kPhases == 1, "two passes of the third product need every output chunk at hand");
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   _Float16* const halo = lds;
   _Float16* const w1s = lds + 16384;   // three stages of [64][64]
   _Float16* const w2s = lds;           // [kK2/64][kRows2][64]
-  _Float16* const w3s = lds + 16384;   // [kCPP][kN3][64]
+  _Float16* const w3s = lds + 16384;   // [kCPP][64][64]: 64 rows of W3, the K columns of the phase
   _Float16* const tiles = lds + 32768;        // 8 x [16 pixels][32 channels]
   _Float16* const b2s = lds + 32768 + 8 * 512;  // the second product's 256 biases
 
@@ -185,24 +189,31 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
 #pragma unroll
   for (int i = 0; i < kW3Vecs; ++i) {
     const int v = i * kThreads + tid;
-    const int cc = v / (kN3 * 8);
-    const int r = (v >> 3) % kN3;
+    const int cc = v / (64 * 8);
+    const int r = (v >> 3) % 64;
     const int chunk = (v & 7) ^ ((r >> 1) & 7);
     w3_off[i] = static_cast<unsigned>((r * kN2 + cc * 64 + chunk * 8) * 2);
   }
+  auto load_w3 = [&](int phase, int pass) {
+#pragma unroll
+    for (int i = 0; i < kW3Vecs; ++i)
+      w3r[i] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, static_cast<int>(w3_off[i]),
+                                                     (pass * 64 * kN2 + phase * kCPP * 64) * 2, 0);
+  };
   auto load_weights = [&](int phase) {
 #pragma unroll
     for (int i = 0; i < kW2Vecs; ++i)
       w2r[i] = __builtin_amdgcn_raw_buffer_load_b128(w2_rsrc, static_cast<int>(w2_off[i]), phase * kRows2 * kK2 * 2, 0);
+    load_w3(phase, 0);
+  };
+  auto store_w3 = [&]() {
 #pragma unroll
-    for (int i = 0; i < kW3Vecs; ++i)
-      w3r[i] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, static_cast<int>(w3_off[i]), phase * kCPP * 64 * 2, 0);
+    for (int i = 0; i < kW3Vecs; ++i) *reinterpret_cast<uint4v*>(w3s + (i * kThreads + tid) * 8) = w3r[i];
   };
   auto store_weights = [&]() {
 #pragma unroll
     for (int i = 0; i < kW2Vecs; ++i) *reinterpret_cast<uint4v*>(w2s + (i * kThreads + tid) * 8) = w2r[i];
-#pragma unroll
-    for (int i = 0; i < kW3Vecs; ++i) *reinterpret_cast<uint4v*>(w3s + (i * kThreads + tid) * 8) = w3r[i];
+    store_w3();
   };
   // Residual rows of all four chunks.  EVERY load of this kernel is issued before its first store: the
   // vector-memory counter retires in order, so a wait for a load issued behind a store would also wait
@@ -290,6 +301,7 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
   store_weights();
   if (tid < 32) *reinterpret_cast<uint4v*>(b2s + tid * 8) = b2v;
   if constexpr (kPhases > 1) load_weights(1);
+  if constexpr (kPasses3 > 1) load_w3(0, 1);  // the second 64 rows of W3: before the first store, like every load
   LdsBarrier();
 
   // ---- second and third product, wave by wave ----------------------------------------------------
@@ -301,12 +313,13 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
   const int tw1 = px * 32 + (((2 + (q >> 1)) ^ tswz) * 8) + (q & 1) * 4;  // channels 16 + 4 q .. + 3
   const int tr = px * 32 + ((q ^ tswz) * 8);                              // channels 8 q .. + 7
   float4v acc3[kNI3];
-  half4 b3[kNI3];  // added at the very end: requested here, long there by then
+  half4 b3[kPasses3 * kNI3];  // added at the very end: requested here, long there by then
 #pragma unroll
-  for (int f = 0; f < kNI3; ++f) {
-    acc3[f] = float4v{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < kNI3; ++f) acc3[f] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < kPasses3 * kNI3; ++f)
     b3[f] = a.bias3 != nullptr ? *reinterpret_cast<const half4*>(a.bias3 + f * 16 + q * 4) : half4{0, 0, 0, 0};
-  }
+  half8 outs[4][2];  // the finished output chunks: activation operand of the third product
 #pragma unroll
   for (int ph = 0; ph < kPhases; ++ph) {
     if (ph > 0) {
@@ -336,7 +349,6 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
       }
       // transposition through the wave's own tile, 32 channels at a time: no barrier, LDS operations of a
       // wave run in order
-      half8 out[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         *reinterpret_cast<half4*>(tile + tw0) = PackRelu(acc2[2 * s], false);
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
         v = v + res[c][s];  // packed fp16 adds (zeros without a residual)
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] > static_cast<_Float16>(0) ? v[j] : static_cast<_Float16>(0);
-        out[s] = v;
+        outs[c][s] = v;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), y_rsrc, static_cast<int>(y_off), (c * 64 + s * 32) * 2, 0);
       }
       // third product: the finished values are its activation operand as they stand
@@ -354,19 +366,44 @@ __global__ __launch_bounds__(kThreads, 4) void BottleneckRowsKernel(RowsArgs a) 
         if (a.ablate & 32) break;
 #pragma unroll
         for (int f = 0; f < kNI3; ++f) {
-          const half8 wf = *reinterpret_cast<const half8*>(w3s + (cc * kN3 + f * 16) * 64 + (frag_off ^ (s * 32)));
-          acc3[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, out[s], acc3[f], 0, 0, 0);
+          const half8 wf = *reinterpret_cast<const half8*>(w3s + (cc * 64 + f * 16) * 64 + (frag_off ^ (s * 32)));
+          acc3[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, outs[c][s], acc3[f], 0, 0, 0);
         }
       }
     }
   }
-  // third result: ReLU, transposed 64 channels at a time through the wave's tile, 16-byte stores
+  // third result: + bias, ReLU, transposed 32 channels at a time through the wave's tile, 16-byte stores
+  auto third_epilogue = [&](int pass) {
 #pragma unroll
-  for (int h = 0; h < kN3 / 32; ++h) {
-    *reinterpret_cast<half4*>(tile + tw0) = PackRelu(acc3[2 * h] + Widen(b3[2 * h]), true);
-    *reinterpret_cast<half4*>(tile + tw1) = PackRelu(acc3[2 * h + 1] + Widen(b3[2 * h + 1]), true);
-    const half8 v = *reinterpret_cast<const half8*>(tile + tr);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), o3_rsrc, static_cast<int>(o3_off), h * 64, 0);
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<half4*>(tile + tw0) = PackRelu(acc3[2 * h] + Widen(b3[pass * kNI3 + 2 * h]), true);
+      *reinterpret_cast<half4*>(tile + tw1) = PackRelu(acc3[2 * h + 1] + Widen(b3[pass * kNI3 + 2 * h + 1]), true);
+      const half8 v = *reinterpret_cast<const half8*>(tile + tr);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, v), o3_rsrc, static_cast<int>(o3_off),
+                                             (pass * 64 + h * 32) * 2, 0);
+    }
+  };
+  third_epilogue(0);
+  if constexpr (kPasses3 > 1) {
+    // the other 64 outputs of the third product: its weights replace the first pass's, the operand is the
+    // output chunks kept in registers
+    LdsBarrier();  // every wave is done with the first 64 rows of W3
+    store_w3();
+    LdsBarrier();
+#pragma unroll
+    for (int f = 0; f < kNI3; ++f) acc3[f] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int f = 0; f < kNI3; ++f) {
+          const half8 wf = *reinterpret_cast<const half8*>(w3s + (c * 64 + f * 16) * 64 + (frag_off ^ (s * 32)));
+          acc3[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, outs[c][s], acc3[f], 0, 0, 0);
+        }
+      }
+    }
+    third_epilogue(1);
   }
 }
 
