@@ -53,16 +53,22 @@ def parse_args():
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the short wire / system-shared-memory comparison runs")
-    ap.add_argument("--extra-requests", type=int, default=4608,
+    ap.add_argument("--extra-requests", type=int, default=12288,
                     help="requests per GPU of each comparison run (wire, system shm)")
     ap.add_argument("--client", choices=["native", "python"], default=os.environ.get("TCA_BENCH_CLIENT", "native"),
                     help="native: C++ load generator (tca_loadgen) over the in-tree gRPC/HTTP client; "
                          "python: tritonclient-API threads in this process")
     ap.add_argument("--connections", type=int, default=8, help="gRPC channels the native load generator spreads over")
-    ap.add_argument("--image-requests", type=int, default=3000,
+    ap.add_argument("--image-requests", type=int, default=16384,
                     help="requests of the end-to-end image pipeline run (extra.image_client)")
     ap.add_argument("--image-lanes", type=int, default=3)
     ap.add_argument("--image-depth", type=int, default=6)
+    ap.add_argument("--sweep", default="1,4,16,64,256",
+                    help="concurrency levels of the HIP shared-memory sweep reported under extra.sweep ('' = none)")
+    ap.add_argument("--sweep-seconds", type=float, default=1.5, help="measured window of every sweep level")
+    ap.add_argument("--secondary-window-ms", type=int, default=2000)
+    ap.add_argument("--generator-timeout", type=float, default=600.0,
+                    help="seconds the load generator may take for one phase before the run is abandoned")
     ap.add_argument("--mode", choices=["serve", "fanout", "image_client"], default="serve",
                     help="fanout: also measure resnet50_sharded (one request's batch split over the GPUs), "
                          "reported under extra.fanout; runs by itself when there are several ranks")
@@ -86,8 +92,85 @@ if not os.path.exists(LOADGEN):
     LOADGEN = os.path.join(ROOT, "build", "bin", "tca_loadgen")
 
 
+def structured_images(count, first=0, height=375, width=500):
+    """Synthetic u8 images with structure - colour gradients in a direction, a checkerboard and a filled
+    rectangle, all derived from the image's index - so that every image is different from every other one in
+    ways that survive resizing: the logits of a random-init network then differ between images by far more
+    than fp16 rounding, and a path that mixed up or ignored its inputs would show."""
+    import numpy as np
+
+    # built at quarter resolution and repeated 4 x 4: a millisecond per image, and features coarse enough to
+    # survive the resize to 224 x 224
+    qh, qw = (height + 3) // 4, (width + 3) // 4
+    yy, xx = np.mgrid[0:qh, 0:qw].astype(np.float32)
+    out = []
+    for k in range(first, first + count):
+        c0 = np.array([(37 * k + 11) % 256, (91 * k + 60) % 256, (53 * k + 120) % 256], dtype=np.float32)
+        c1 = np.array([(101 * k + 200) % 256, (17 * k + 5) % 256, (149 * k + 77) % 256], dtype=np.float32)
+        t = (xx / qw, yy / qh, (xx + yy) / (qw + qh), (xx / qw - yy / qh + 1.0) / 2.0)[k % 4]
+        img = c0[None, None, :] * (1.0 - t[..., None]) + c1[None, None, :] * t[..., None]
+        block = 3 + 2 * (k % 7)
+        checker = (((xx // block) + (yy // block)) % 2) * 2.0 - 1.0
+        img += 35.0 * checker[..., None] * np.array([1.0, -1.0, 0.5], dtype=np.float32)[(k // 3) % 3]
+        y0, x0 = (7 * k) % (qh // 2), (11 * k) % (qw // 2)
+        img[y0:y0 + qh // 3, x0:x0 + qw // 3, k % 3] = (200 + 13 * k) % 256
+        small = np.clip(img, 0, 255).astype(np.uint8)
+        out.append(np.ascontiguousarray(small.repeat(4, axis=0).repeat(4, axis=1)[:height, :width]))
+    return out
+
+
+def read_line(proc, timeout, what):
+    """One line of the load generator's stdout, or an error once ``timeout`` seconds have passed without one
+    (a generator that stalls must not hold the rank until the driver's own limit)."""
+    import select
+
+    ready, _, _ = select.select([proc.stdout], [], [], timeout)
+    if not ready:
+        proc.kill()
+        raise RuntimeError(f"load generator: no {what} within {timeout:.0f} s")
+    return proc.stdout.readline()
+
+
+def check_contents(args, device, slots, hipshm):
+    """Reads the input and output regions of a few slots back and compares the served logits with a forward of
+    the same inputs by a model instance loaded in THIS process (same seeded random-init weights).  The server
+    merges requests into batches of other sizes, which run other tile variants, so the comparison is to fp16
+    rounding, not bit for bit; the images differ (structured_images), so do the logits, and that is asserted."""
+    import numpy as np
+    import torch
+
+    from triton_client_amd.models import MODEL_ZOO
+
+    b = args.batch
+    model = MODEL_ZOO[args.model]()
+    model.load(device)
+    try:
+        served, direct = [], []
+        for hin, hout in slots:
+            x = hipshm.get_contents_as_numpy(hin, np.float16, [b, 3, 224, 224])
+            served.append(np.array(hipshm.get_contents_as_numpy(hout, np.float32, [b, 1000]), copy=True))
+            xt = torch.from_numpy(np.array(x, copy=True)).to(f"cuda:{device}")
+            out = model.run(xt)
+            model.stream.synchronize()
+            direct.append(out.float().cpu().numpy())
+        served, direct = np.concatenate(served), np.concatenate(direct)
+    finally:
+        model.unload()
+    err = float(np.abs(served - direct).max())
+    scale = float(np.abs(direct).max())
+    # how far apart the logits of two different images are at least (every pair of the checked images)
+    n = served.shape[0]
+    apart = min(float(np.abs(served[i] - served[j]).max()) for i in range(n) for j in range(i + 1, n))
+    ok = bool(np.isfinite(served).all() and err <= 0.05 * scale and apart > 4.0 * err
+              and (served.argmax(1) == direct.argmax(1)).mean() >= 0.9)
+    return {"max_abs_err": round(err, 5), "logit_scale": round(scale, 4), "images_checked": int(n),
+            "min_distance_between_images": round(apart, 4),
+            "top1_agreement": round(float((served.argmax(1) == direct.argmax(1)).mean()), 4),
+            "reference": "model.run of the same input regions in the benchmark process (batch 8)", "ok": ok}
+
+
 def measure_native(args, url, device, dist, label, mode=None, steps=None, per_step=None, warmup_requests=None,
-                   model=None, batch=None, concurrency=None):
+                   model=None, batch=None, concurrency=None, check=False, sweep=None):
     """Closed loop driven by the C++ load generator.  This process only prepares
     the tensors (HIP preprocessing kernel -> HIP shared-memory regions, or system
     shared memory, or nothing for tensors on the wire), registers the regions and
@@ -114,9 +197,12 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
     model = model or args.model
     concurrency = concurrency or args.concurrency
     in_bytes, out_bytes = b * 3 * 224 * 224 * 2, b * 1000 * 4
-    rng = np.random.default_rng(1234 + device)
-    images = [rng.integers(0, 256, size=(375, 500, 3), dtype=np.uint8) for _ in range(b)]
+    images = structured_images(b, first=1000 * device)
     pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=device, max_batch=max(8, min(b, 64)))
+    extra = {}
+    image_sets = {0: images}
+    levels = [int(v) for v in (sweep or [])]
+    slots_wanted = max([concurrency] + levels)
     control = grpcclient.InferenceServerClient(url if args.protocol == "grpc" else args.control_url)
     regions = []
     cleanup = []
@@ -141,14 +227,19 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
         if mode == "hip":
             import tritonclient.utils.cuda_shared_memory as hipshm
 
-            for i in range(concurrency):
+            for i in range(slots_wanted):
                 hin = hipshm.create_shared_memory_region(f"in_{device}_{i}", in_bytes, device)
                 hout = hipshm.create_shared_memory_region(f"out_{device}_{i}", out_bytes, device)
                 regions += [hin, hout]
                 if tiled is not None:
                     hipshm.set_shared_memory_region_from_dlpack(hin, [tiled])
                 else:
-                    pre(images, hin)  # HIP kernel writes the batch straight into the region
+                    # every slot its own images; the HIP kernel writes the batch straight into the region
+                    # (the sweep's extra slots repeat the image sets of the first 64)
+                    key = i % 64
+                    if key not in image_sets:
+                        image_sets[key] = structured_images(b, first=1000 * device + key * b)
+                    pre(image_sets[key], hin)
                 control.register_cuda_shared_memory(f"in_{device}_{i}", hipshm.get_raw_handle(hin), device, in_bytes)
                 control.register_cuda_shared_memory(f"out_{device}_{i}", hipshm.get_raw_handle(hout), device, out_bytes)
                 cleanup.append(lambda i=i: (control.unregister_cuda_shared_memory(f"in_{device}_{i}"),
@@ -179,20 +270,30 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
         else:
             cmd += ["--shape", f"input:FP16:{b},3,224,224"]  # 1.2 MB of tensor bytes in every request
         proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
-        ready = proc.stdout.readline().strip()
+        ready = read_line(proc, args.generator_timeout, "READY line (warm-up)").strip()
         if ready != "READY":
             raise RuntimeError(f"load generator did not get ready: {ready!r}")
         barrier()
         t0 = time.perf_counter()
         proc.stdin.write("GO\n")
         proc.stdin.flush()
-        result = json.loads(proc.stdout.readline())
+        result = json.loads(read_line(proc, args.generator_timeout, "result of the measured phase"))
         barrier()
         elapsed = time.perf_counter() - t0
         proc.wait(timeout=30)
         if result["errors"] or result["requests"] != steps * per_step:
             raise RuntimeError(f"load generator reported {result['errors']} errors "
                                f"({result['requests']} of {steps * per_step} requests): {result['first_error']}")
+        if check and mode == "hip" and tiled is None:
+            try:
+                # slots far apart: their requests were merged into different batches
+                picks = sorted({0, concurrency // 3, (2 * concurrency) // 3, concurrency - 1})
+                extra["check"] = check_contents(args, device, [(regions[2 * i], regions[2 * i + 1]) for i in picks],
+                                                hipshm)
+            except Exception as e:  # noqa: BLE001 - reported in the line; the throughput result stands
+                extra["check"] = {"error": f"{type(e).__name__}: {e}"[:400], "ok": False}
+        if levels and mode == "hip":
+            extra["sweep"] = run_sweep(args, cmd, levels, barrier, dist, b)
     finally:
         if proc is not None and proc.poll() is None:
             proc.kill()
@@ -220,7 +321,49 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
     return {"label": label, "infer_per_sec": world * steps * per_step * b / elapsed, "elapsed_s": elapsed,
             "p50_us": pcts[0], "p90_us": pcts[1], "p95_us": pcts[2], "p99_us": pcts[3],
             "generator_infer_per_sec": result["infer_per_sec"], "per_gpu_infer_per_sec": per_gpu,
-            "requests": world * steps * per_step}
+            "requests": world * steps * per_step, **extra}
+
+
+def run_sweep(args, base_cmd, levels, barrier, dist, b):
+    """Concurrency sweep over the slots' HIP shared-memory regions, the load generator in its timed mode: every
+    level warms up, then records ``--sweep-seconds``.  With several ranks every rank sweeps its own server at the
+    same time: throughputs are summed, latencies are the worst rank's."""
+    import subprocess
+
+    import torch
+
+    def replaced(cmd, flag, value):
+        cmd = list(cmd)
+        cmd[cmd.index(flag) + 1] = str(value)
+        return cmd
+
+    base = [a for a in base_cmd if a != "--wait-go"]
+    for flag in ("--count", "--warmup-count"):  # timed mode: no request counts
+        i = base.index(flag)
+        del base[i:i + 2]
+    out = []
+    for c in levels:
+        cmd = replaced(base, "-c", c) + ["-d", str(args.sweep_seconds), "--warmup", "0.4"]
+        barrier()
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+        try:
+            r = json.loads(read_line(proc, args.sweep_seconds + 60.0, f"result of sweep level {c}"))
+            proc.wait(timeout=30)
+        finally:
+            if proc.poll() is None:
+                proc.kill()
+        if r["errors"]:
+            raise RuntimeError(f"sweep level {c}: {r['errors']} errors: {r['first_error']}")
+        vals = [r["infer_per_sec"], r["p50_us"], r["p99_us"], r["duration_s"]]
+        if dist is not None:
+            t = torch.tensor(vals[:1], device=args.reduce_device, dtype=torch.float64)
+            dist.all_reduce(t)
+            m = torch.tensor(vals[1:], device=args.reduce_device, dtype=torch.float64)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+            vals = [float(t[0].item())] + [float(v) for v in m.tolist()]
+        out.append({"concurrency_per_gpu": c, "infer_per_sec": round(vals[0], 1), "p50_latency_us": round(vals[1], 1),
+                    "p99_latency_us": round(vals[2], 1), "window_s": round(vals[3], 3), "request_batch": b})
+    return out
 
 
 class Worker:
@@ -401,8 +544,8 @@ def measure_image_client(args, url, device):
 
     from triton_client_amd.pipeline import ImagePipeline
 
-    rng = np.random.default_rng(99 + device)
-    batches = [[rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8) for _ in range(args.batch)] for _ in range(4)]
+    batches = [structured_images(args.batch, first=5000 + 1000 * device + k * args.batch, height=480, width=640)
+               for k in range(4)]
     pipe = ImagePipeline(url, args.model, batch=args.batch, lanes=args.image_lanes, depth=args.image_depth,
                          classes=3, device=device)
     try:
@@ -424,7 +567,7 @@ def measure_secondary(args, device, dist):
     `simple` over HTTP + system shared memory, `simple` over gRPC with tensors on the wire,
     `simple_string` (BYTES) over gRPC + HIP shared memory, `repeat_int32` (decoupled, 16 responses
     per request) and `simple_sequence` (stateful, sequences of 20 requests) over gRPC streams.
-    Closed loop at concurrency 16, two 1 s windows each; with
+    Closed loop at concurrency 16, two windows of ``--secondary-window-ms`` each; with
     several ranks the throughputs are summed over the GPUs and the latencies are the worst rank's."""
     import contextlib
 
@@ -437,7 +580,7 @@ def measure_secondary(args, device, dist):
     rates, lats, error = [0.0] * len(names), [0.0] * (2 * len(names)), None
     try:
         with contextlib.redirect_stdout(sys.stderr):  # the analyzer reports on stdout; ours carries one JSON line
-            lines = {line["config"]: line for line in run_configs(gpu=device, window_ms=1000)}
+            lines = {line["config"]: line for line in run_configs(gpu=device, window_ms=args.secondary_window_ms)}
         for i, name in enumerate(names):
             line = lines[name]
             rates[i] = float(line["responses_per_sec"] if name == "decoupled_stream" else line["infer_per_sec"])
@@ -655,8 +798,14 @@ def main():
         url = server.grpc_url if args.protocol == "grpc" else server.http_url
         args.control_url = server.grpc_url
         run = measure_native if args.client == "native" else measure
-        main_result = run(args, url, device, dist, f"{args.protocol}+{args.shared_memory}shm")
+        main_kwargs = {}
+        if args.client == "native" and not args.no_extras and args.mode == "serve":
+            main_kwargs = {"check": True, "sweep": [v for v in args.sweep.split(",") if v.strip()]}
+        main_result = run(args, url, device, dist, f"{args.protocol}+{args.shared_memory}shm", **main_kwargs)
         extras = {}
+        for key in ("check", "sweep"):
+            if key in main_result:
+                extras[key] = main_result.pop(key)
         if not args.no_extras and args.client == "native":
             # the same requests with the tensors inside the messages / in system shared memory:
             # short runs, same server, same generator, same concurrency
@@ -712,7 +861,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "fp16",
-            "data": "synthetic images (375x500 u8) through the HIP preprocessing kernel; random-init ResNet-50 weights",
+            "data": "synthetic structured images (375x500 u8, different in every slot) through the HIP preprocessing "
+                    "kernel; random-init ResNet-50 weights",
             "p50_latency_us": round(main_result["p50_us"], 1),
             "p90_latency_us": round(main_result["p90_us"], 1),
             "p95_latency_us": round(main_result["p95_us"], 1),
@@ -721,7 +871,7 @@ def main():
             "rank_backend": ("rccl" if args.dist_backend == "nccl" else "gloo") if n > 1 else None,
             "per_gpu_infer_per_sec": [round(v, 1) for v in main_result.get("per_gpu_infer_per_sec", [])],
             "config": {
-                "model": "resnet50",
+                "model": args.model,
                 "batch": args.batch,
                 "global_batch": args.batch * args.concurrency * n,
                 "seq_len": None,
