@@ -215,6 +215,99 @@ PyObject* Quiesce(PyObject* self_obj, PyObject*) {
   Py_RETURN_NONE;
 }
 
+// enable_graph_model(name, entry_points, device, streams, graphs, in_row_bytes, out_row_bytes, max_batch,
+//                    max_inflight, fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap)
+// entry_points: addresses of (graph_launch, event_create, event_record, event_sync, event_destroy, set_device,
+// batched_copy); streams: one handle per execution instance; graphs: (instance, batch, exec, in_ptr, out_ptr).
+PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = nullptr;
+  PyObject *entry = nullptr, *streams = nullptr, *graphs = nullptr;
+  int device = 0, max_batch = 0, max_inflight = 0, fill = 0, gap = 300, window = 100, split = 16, adaptive = 1;
+  unsigned long long in_row = 0, out_row = 0;
+  if (!PyArg_ParseTuple(args, "sOiOOKKiiiiiip", &name, &entry, &device, &streams, &graphs, &in_row, &out_row, &max_batch,
+                        &max_inflight, &fill, &gap, &window, &split, &adaptive))
+    return nullptr;
+  tca::server::NativeExecutor::GraphPipe p;
+  unsigned long long fn[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (!PyArg_ParseTuple(entry, "KKKKKKK", &fn[0], &fn[1], &fn[2], &fn[3], &fn[4], &fn[5], &fn[6])) return nullptr;
+  p.graph_launch = reinterpret_cast<decltype(p.graph_launch)>(static_cast<uintptr_t>(fn[0]));
+  p.event_create = reinterpret_cast<decltype(p.event_create)>(static_cast<uintptr_t>(fn[1]));
+  p.event_record = reinterpret_cast<decltype(p.event_record)>(static_cast<uintptr_t>(fn[2]));
+  p.event_sync = reinterpret_cast<decltype(p.event_sync)>(static_cast<uintptr_t>(fn[3]));
+  p.event_destroy = reinterpret_cast<decltype(p.event_destroy)>(static_cast<uintptr_t>(fn[4]));
+  p.set_device = reinterpret_cast<decltype(p.set_device)>(static_cast<uintptr_t>(fn[5]));
+  p.batched_copy = reinterpret_cast<decltype(p.batched_copy)>(static_cast<uintptr_t>(fn[6]));
+  PyObject* seq = PySequence_Fast(streams, "streams must be a sequence of handles");
+  if (seq == nullptr) return nullptr;
+  for (Py_ssize_t i = 0; i < PySequence_Fast_GET_SIZE(seq); ++i) {
+    const unsigned long long h = PyLong_AsUnsignedLongLong(PySequence_Fast_GET_ITEM(seq, i));
+    if (PyErr_Occurred()) {
+      Py_DECREF(seq);
+      return nullptr;
+    }
+    p.streams.push_back(reinterpret_cast<void*>(static_cast<uintptr_t>(h)));
+  }
+  Py_DECREF(seq);
+  seq = PySequence_Fast(graphs, "graphs must be a sequence of (instance, batch, exec, in_ptr, out_ptr)");
+  if (seq == nullptr) return nullptr;
+  for (Py_ssize_t i = 0; i < PySequence_Fast_GET_SIZE(seq); ++i) {
+    tca::server::NativeExecutor::GraphPipe::Graph g;
+    unsigned long long exec = 0, in_ptr = 0, out_ptr = 0;
+    if (!PyArg_ParseTuple(PySequence_Fast_GET_ITEM(seq, i), "iiKKK", &g.instance, &g.batch, &exec, &in_ptr, &out_ptr)) {
+      Py_DECREF(seq);
+      return nullptr;
+    }
+    g.exec = reinterpret_cast<void*>(static_cast<uintptr_t>(exec));
+    g.in_ptr = in_ptr;
+    g.out_ptr = out_ptr;
+    p.graphs.push_back(g);
+  }
+  Py_DECREF(seq);
+  p.device = device;
+  p.in_row_bytes = in_row;
+  p.out_row_bytes = out_row;
+  p.max_batch = max_batch;
+  p.max_inflight = max_inflight;
+  p.fill_window_us = fill;
+  p.burst_gap_us = gap;
+  p.burst_window_us = window;
+  p.split_min_batch = split;
+  p.adaptive_cap = adaptive != 0;
+  const std::string model(name);
+  tca::Error e;
+  Py_BEGIN_ALLOW_THREADS
+  e = (*self->ex)->EnableGraphModel(model, p);
+  Py_END_ALLOW_THREADS
+  if (!e.IsOk()) {
+    PyErr_SetString(PyExc_ValueError, e.Message().c_str());
+    return nullptr;
+  }
+  Py_RETURN_NONE;
+}
+
+PyObject* DisableGraphModel(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = "";
+  if (!PyArg_ParseTuple(args, "|s", &name)) return nullptr;
+  const std::string model(name);
+  Py_BEGIN_ALLOW_THREADS  // answers in flight may need the interpreter lock to be delivered
+  (*self->ex)->DisableGraphModel(model);
+  Py_END_ALLOW_THREADS
+  Py_RETURN_NONE;
+}
+
+PyObject* GraphStats(PyObject* self_obj, PyObject* args) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  const char* name = nullptr;
+  if (!PyArg_ParseTuple(args, "s", &name)) return nullptr;
+  tca::server::NativeExecutor::GraphCounters c;
+  if (!(*self->ex)->GraphStats(name, &c)) Py_RETURN_NONE;
+  return Py_BuildValue("{s:K,s:K,s:K,s:K}", "batches", static_cast<unsigned long long>(c.batches), "requests",
+                       static_cast<unsigned long long>(c.requests), "images", static_cast<unsigned long long>(c.images),
+                       "padded_images", static_cast<unsigned long long>(c.padded_images));
+}
+
 PyObject* RegisterDeviceRegion(PyObject* self_obj, PyObject* args) {
   auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
   const char* name = nullptr;
@@ -273,6 +366,11 @@ PyMethodDef kMethods[] = {
      "enable_device_bytes(submit_address, wait_address, pipe, stream, device, max_requests, max_count, max_stream_bytes)"},
     {"disable_device_bytes", DisableDeviceBytes, METH_NOARGS, "answers what is queued and stops the batch thread"},
     {"quiesce", Quiesce, METH_NOARGS, "blocks until no deferred request is queued or running"},
+    {"enable_graph_model", EnableGraphModel, METH_VARARGS,
+     "enable_graph_model(name, entry_points, device, streams, graphs, in_row_bytes, out_row_bytes, max_batch, max_inflight, "
+     "fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap)"},
+    {"disable_graph_model", DisableGraphModel, METH_VARARGS, "disable_graph_model([name]): answers what is queued and stops the threads"},
+    {"graph_stats", GraphStats, METH_VARARGS, "graph_stats(name) -> batches / requests / images / padded_images, or None"},
     {"register_device_region", RegisterDeviceRegion, METH_VARARGS, "register_device_region(name, address, byte_size, device)"},
     {"unregister_device_region", UnregisterDeviceRegion, METH_VARARGS,
      "unregister_device_region([name[, timeout_ms]]) -> False when requests still use the region"},

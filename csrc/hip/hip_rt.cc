@@ -77,6 +77,35 @@ int tca_hip_memcpy_async(void* dst, const void* src, uint64_t bytes, int kind, v
   return 0;
 }
 
+// Captured graphs and events for callers that only hold raw handles (the native serving path replays
+// graphs that PyTorch captured: `exec` is a hipGraphExec_t).
+int tca_hip_graph_launch(void* exec, void* stream) {
+  RT_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(exec), static_cast<hipStream_t>(stream)), "hipGraphLaunch");
+  return 0;
+}
+
+int tca_hip_event_create(void** event) {
+  hipEvent_t e;
+  RT_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
+  *event = e;
+  return 0;
+}
+
+int tca_hip_event_record(void* event, void* stream) {
+  RT_TRY(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)), "hipEventRecord");
+  return 0;
+}
+
+int tca_hip_event_sync(void* event) {
+  RT_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)), "hipEventSynchronize");
+  return 0;
+}
+
+int tca_hip_event_destroy(void* event) {
+  RT_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)), "hipEventDestroy");
+  return 0;
+}
+
 int tca_hip_memset_async(void* dst, int value, uint64_t bytes, void* stream) {
   RT_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)), "hipMemsetAsync");
   return 0;

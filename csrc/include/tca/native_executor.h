@@ -29,6 +29,19 @@
 // three kernel launches per group) and answers them from there (TryGrpcAsync).  The pipeline
 // itself lives in the HIP library; this file only sees its C entry points (DevicePipe).
 //
+// GPU models whose forward pass is a set of captured HIP graphs ("graph" on `resnet50`; the model
+// contract is the image classifier the reference's `src/python/examples/image_client.py:59-150` and
+// perf tools drive: one fixed-size input, one vector output, a batch dimension): a request whose
+// tensors are in device shared memory is decoded on the reactor thread and queued; a batch thread
+// merges requests along the batch axis with the serving policy of the dynamic batcher (absorb
+// arrivals while the GPU is full, fill window, burst window, a cap that follows the load, halves on
+// two idle instances), gathers the inputs into the static buffer of the smallest captured graph
+// that holds the batch (padding: rows past the batch are computed and ignored), launches the graph
+// and scatters the outputs into the callers' regions - three launches per batch, no interpreter -
+// and one completer thread per execution instance waits for the batch's event and answers.  The
+// graphs, their buffers and the streams stay owned by the Python model; this file only sees HIP
+// through the C entry points in GraphPipe.
+//
 // Statistics are accumulated here and collected by the Python core (TakeStats), so the
 // model statistics endpoints keep counting requests that never reached Python.
 #pragma once
@@ -63,7 +76,33 @@ class NativeExecutor {
     std::string name, version;  // version = the one unversioned requests resolve to
     int max_batch = 0;
     std::vector<TensorSpec> inputs, outputs;
-    std::string kernel;  // "add_sub" | "identity" | "repeat" | "bytes_add_sub" | "bytes_identity"
+    std::string kernel;  // "add_sub" | "identity" | "repeat" | "bytes_add_sub" | "bytes_identity" | "graph" ...
+  };
+  // Captured forward graphs of one GPU model and the HIP entry points to run them (all owned by the
+  // caller, alive until DisableGraphModel has returned).
+  struct GraphPipe {
+    int (*graph_launch)(void* exec, void* stream) = nullptr;
+    int (*event_create)(void** event) = nullptr;
+    int (*event_record)(void* event, void* stream) = nullptr;
+    int (*event_sync)(void* event) = nullptr;
+    int (*event_destroy)(void* event) = nullptr;
+    int (*set_device)(int device) = nullptr;
+    int (*batched_copy)(const void* const* srcs, void* const* dsts, const uint64_t* bytes, int n, void* stream) = nullptr;
+    int device = 0;
+    std::vector<void*> streams;  // one per execution instance
+    struct Graph {
+      int instance = 0, batch = 0;
+      void* exec = nullptr;
+      uint64_t in_ptr = 0, out_ptr = 0;  // static buffers the graph reads / writes: [batch][row bytes]
+    };
+    std::vector<Graph> graphs;
+    uint64_t in_row_bytes = 0, out_row_bytes = 0;  // per batch entry
+    int max_batch = 0;
+    int max_inflight = 0;  // batches enqueued on the GPU at once (0: two per instance)
+    // batching policy, microseconds (see server/batcher.py for what each one is for)
+    int fill_window_us = 0, burst_gap_us = 300, burst_window_us = 100;
+    int split_min_batch = 16;
+    bool adaptive_cap = true;
   };
   // C entry points of the device BYTES pipeline (`csrc/hip/bytes_models.hip`) plus one pipeline
   // object and the stream its batches run on; all owned by the caller, alive until
@@ -115,6 +154,16 @@ class NativeExecutor {
   bool UnregisterDeviceRegion(const std::string& name, int timeout_ms);
   // Blocks until no deferred request is queued or running.
   void Quiesce();
+  // Starts (or restarts) the batch and completer threads that serve `model` (registered with the "graph"
+  // kernel) from its captured graphs.
+  Error EnableGraphModel(const std::string& model, const GraphPipe& pipe);
+  // Answers what is queued for `model` ("" = every graph model), then stops its threads.
+  void DisableGraphModel(const std::string& model);
+  // Batches launched, requests merged into them and rows computed beyond the merged batches (padding), per model.
+  struct GraphCounters {
+    uint64_t batches = 0, requests = 0, images = 0, padded_images = 0;
+  };
+  bool GraphStats(const std::string& model, GraphCounters* out);
 
   // `request` = serialized ModelInferRequest; true: `response` holds the serialized ModelInferResponse.
   bool TryGrpc(const std::string& request, std::string* response);
@@ -173,6 +222,16 @@ class NativeExecutor {
   struct Request;
   struct Result;
   struct DeviceJob;
+  struct GraphJob;
+  class GraphRunner;
+  friend class GraphRunner;
+  bool PrepareGraphJob(Request* req, const std::shared_ptr<Model>& model, const GraphRunner& runner, GraphJob* job);
+  std::shared_ptr<GraphRunner> FindRunner(const std::string& model);
+  // Validates and queues a request for a graph model (`bytes`: the request message / body, moved on kDeferred).
+  Outcome SubmitGraph(Request* req, const std::shared_ptr<Model>& model, std::string* bytes, Completion done,
+                      HttpCompletion http_done);
+  void QuiesceGraphModels();
+  void FinishGraphJob(GraphJob* job, bool ok, uint64_t t_exec, uint64_t t_enq, uint64_t t_done, bool first);
   bool PrepareDeviceJob(Request* req, const std::shared_ptr<Model>& model, DeviceJob* job);
   void DeviceLoop();
   void FinishDeviceJob(DeviceJob* job, bool ok);
@@ -193,6 +252,7 @@ class NativeExecutor {
   std::map<std::string, std::shared_ptr<Model>> models_;
   std::map<std::string, std::shared_ptr<Region>> regions_;
   std::map<std::string, std::shared_ptr<DeviceRegion>> device_regions_;
+  std::map<std::string, std::shared_ptr<GraphRunner>> runners_;  // graph models being served
 
   // device BYTES path
   DevicePipe pipe_;

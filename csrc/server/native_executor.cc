@@ -6,18 +6,20 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <thread>
 
 #include "tca/json.h"
 #include "tca/pbwire.h"
+#include "tca/sync.h"
 
 namespace tca {
 namespace server {
 namespace {
 
-enum Kernel { kAddSub = 1, kIdentity = 2, kRepeat = 3, kBytesAddSub = 4, kBytesIdentity = 5, kSequence = 6, kDynaSequence = 7 };
+enum Kernel { kAddSub = 1, kIdentity = 2, kRepeat = 3, kBytesAddSub = 4, kBytesIdentity = 5, kSequence = 6, kDynaSequence = 7, kGraph = 8 };
 
 size_t ItemSize(const std::string& dt) {
   if (dt == "INT8" || dt == "UINT8" || dt == "BOOL") return 1;
@@ -126,7 +128,10 @@ NativeExecutor::Region::~Region() {
 
 NativeExecutor::NativeExecutor() = default;
 
-NativeExecutor::~NativeExecutor() { DisableDeviceBytes(); }
+NativeExecutor::~NativeExecutor() {
+  DisableGraphModel(std::string());
+  DisableDeviceBytes();
+}
 
 Error NativeExecutor::SetModel(const ModelSpec& spec) {
   auto m = std::make_shared<Model>();
@@ -158,6 +163,19 @@ Error NativeExecutor::SetModel(const ModelSpec& spec) {
     std::unique_lock<std::shared_mutex> lk(mu_);
     models_[spec.name] = std::move(m);
     return Error::Success();
+  } else if (spec.kernel == "graph") {
+    // a GPU model served from captured graphs: one fixed-size input, one fixed-size output, a batch dimension
+    if (spec.max_batch < 1 || spec.inputs.size() != 1 || spec.outputs.size() != 1 ||
+        ItemSize(spec.inputs[0].datatype) == 0 || ItemSize(spec.outputs[0].datatype) == 0)
+      return Error("graph needs one fixed-type input, one fixed-type output and a batch dimension");
+    for (const auto* t : {&spec.inputs[0], &spec.outputs[0]})
+      for (int64_t d : t->dims)
+        if (d < 1) return Error("graph needs fixed tensor shapes");
+    m->kernel = kGraph;
+    m->itemsize = ItemSize(spec.inputs[0].datatype);
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    models_[spec.name] = std::move(m);
+    return Error::Success();
   } else if (spec.kernel == "repeat") {
     // decoupled: IN INT32[-1], DELAY UINT32[-1], WAIT UINT32[1] -> one response (OUT INT32[1], IDX UINT32[1]) per element
     if (spec.max_batch != 0 || spec.inputs.size() != 3 || spec.outputs.size() != 2) return Error("repeat needs IN, DELAY, WAIT and OUT, IDX");
@@ -183,6 +201,7 @@ Error NativeExecutor::SetModel(const ModelSpec& spec) {
 }
 
 void NativeExecutor::RemoveModel(const std::string& name) {
+  DisableGraphModel(name);  // no-op for every other kernel
   std::unique_lock<std::shared_mutex> lk(mu_);
   models_.erase(name);
 }
@@ -266,6 +285,7 @@ bool NativeExecutor::TakeStats(const std::string& name, Stats* out) {
 // Validates the decoded request against the model exactly as far as needed to be sure the general
 // path would accept it too, then runs the kernel.  False = not ours (nothing has been written).
 bool NativeExecutor::Run(Request* req, const std::shared_ptr<Model>& model) {
+  if (model->kernel == kGraph) return false;  // only through the deferred entry points
   const ModelSpec& spec = model->spec;
   const uint64_t t0 = NowNs();
   const bool stateful = model->kernel == kSequence || model->kernel == kDynaSequence;
@@ -873,8 +893,11 @@ bool NativeExecutor::UnregisterDeviceRegion(const std::string& name, int timeout
 }
 
 void NativeExecutor::Quiesce() {
-  std::unique_lock<std::mutex> lk(q_mu_);
-  idle_cv_.wait(lk, [this] { return queue_.empty() && running_ == 0; });
+  {
+    std::unique_lock<std::mutex> lk(q_mu_);
+    idle_cv_.wait(lk, [this] { return queue_.empty() && running_ == 0; });
+  }
+  QuiesceGraphModels();
 }
 
 // Validates a request for a BYTES model as far as the general path would before it queues the request
@@ -1057,6 +1080,7 @@ NativeExecutor::Outcome NativeExecutor::TryGrpcAsync(std::string* request, std::
   std::shared_ptr<Model> model;
   if (!ParseGrpc(*request, false, &req, &model)) return Outcome::kDeclined;
   if (model->kernel == kRepeat) return Outcome::kDeclined;
+  if (model->kernel == kGraph) return SubmitGraph(&req, model, request, std::move(done), HttpCompletion());
   if (model->kernel == kBytesAddSub || model->kernel == kBytesIdentity) {
     auto job = std::make_unique<DeviceJob>();
     if (!pipe_on_.load(std::memory_order_acquire) || !PrepareDeviceJob(&req, model, job.get())) {
@@ -1095,6 +1119,514 @@ NativeExecutor::Outcome NativeExecutor::TryGrpcAsync(std::string* request, std::
   }
   handled_.fetch_add(1, std::memory_order_relaxed);
   return Outcome::kAnswered;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GPU models served from captured graphs
+// ---------------------------------------------------------------------------------------------
+struct NativeExecutor::GraphJob {
+  Request req;  // results already describe the answer; the scatter copy fills the region
+  std::shared_ptr<Model> model;
+  std::string request_bytes;  // handed back when the launch fails
+  Completion done;            // gRPC caller ...
+  HttpCompletion http_done;   // ... or HTTP caller
+  int batch = 1;
+  uint64_t in_ptr = 0, out_ptr = 0;
+  std::vector<std::shared_ptr<DeviceRegion>> leases;
+  uint64_t t_queued = 0;
+  uint64_t gap_ns = ~0ull >> 2;  // since the previous arrival for this model
+};
+
+class NativeExecutor::GraphRunner {
+ public:
+  GraphRunner(NativeExecutor* owner, const GraphPipe& pipe) : owner_(owner), pipe_(pipe) {
+    for (size_t i = 0; i < pipe_.streams.size(); ++i) {
+      instances_.push_back(std::make_unique<Instance>());
+      instances_[i]->stream = pipe_.streams[i];
+    }
+    for (const auto& g : pipe_.graphs) instances_[static_cast<size_t>(g.instance)]->graphs.push_back(g);
+    for (auto& inst : instances_)
+      std::sort(inst->graphs.begin(), inst->graphs.end(), [](const GraphPipe::Graph& a, const GraphPipe::Graph& b) { return a.batch < b.batch; });
+    cap_ = pipe_.max_inflight > 0 ? pipe_.max_inflight : 2 * static_cast<int>(instances_.size());
+    batch_thread_ = std::thread([this] { BatchLoop(); });
+    for (size_t i = 0; i < instances_.size(); ++i)
+      instances_[i]->completer = std::thread([this, i] { CompleteLoop(static_cast<int>(i)); });
+  }
+  ~GraphRunner() { Stop(); }
+  const GraphPipe& pipe() const { return pipe_; }
+
+  // False: the runner is stopping; `*job` is untouched.
+  bool Submit(std::unique_ptr<GraphJob>* job) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (stop_) return false;
+      const uint64_t now = NowNs();
+      (*job)->t_queued = now;
+      (*job)->gap_ns = now - last_arrival_ns_;
+      last_arrival_ns_ = now;
+      queue_.push_back(std::move(*job));
+    }
+    cv_.notify_all();
+    return true;
+  }
+
+  // Answers everything queued or running, then joins the threads.
+  void Stop() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (stop_ && !batch_thread_.joinable()) return;
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (batch_thread_.joinable()) batch_thread_.join();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      completers_stop_ = true;
+    }
+    for (auto& inst : instances_) inst->cv.notify_all();
+    for (auto& inst : instances_)
+      if (inst->completer.joinable()) inst->completer.join();
+    for (auto& inst : instances_) {
+      for (void* e : inst->free_events) pipe_.event_destroy(e);
+      inst->free_events.clear();
+    }
+  }
+
+  void WaitIdle() {
+    std::unique_lock<std::mutex> lk(mu_);
+    idle_cv_.wait(lk, [this] { return queue_.empty() && running_ == 0; });
+  }
+
+  void Counters(GraphCounters* out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    *out = counters_;
+  }
+
+ private:
+  struct Launched {
+    void* event = nullptr;
+    std::vector<std::unique_ptr<GraphJob>> jobs;
+    int total = 0;
+    uint64_t t_exec = 0, t_enq = 0;
+  };
+  struct Instance {
+    std::vector<GraphPipe::Graph> graphs;  // ascending batch
+    void* stream = nullptr;
+    int busy = 0;  // batches enqueued, not completed
+    std::deque<Launched> launched;
+    std::condition_variable cv;
+    std::vector<void*> free_events;
+    std::thread completer;
+  };
+  using Clock = std::chrono::steady_clock;
+
+  int MinBusy() const {
+    int m = instances_[0]->busy;
+    for (const auto& inst : instances_) m = std::min(m, inst->busy);
+    return m;
+  }
+
+  // The serving policy of the dynamic batcher (server/batcher.py: _next_group), on one lock:
+  // everything already queued joins the batch; while the GPU has no free slot waiting costs nothing, so
+  // arrivals keep being absorbed; with a slot the batch goes at once unless the arrivals look like a burst
+  // (then up to burst_window) or every instance still has work (then up to fill_window, looked at again
+  // every 200 us); with few images around the batch is capped so that every instance gets one.
+  void BatchLoop() {
+    if (pipe_.set_device != nullptr) pipe_.set_device(pipe_.device);
+    const auto us = [](int v) { return std::chrono::microseconds(v); };
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
+      if (queue_.empty()) return;  // stopping, and everything has been launched
+      std::vector<std::unique_ptr<GraphJob>> group;
+      group.push_back(std::move(queue_.front()));
+      queue_.pop_front();
+      int total = group[0]->batch;
+      const auto t_first = Clock::now();
+      auto deadline = t_first;
+      bool have_slot = false;
+      int cap = pipe_.max_batch;
+      if (pipe_.adaptive_cap) {
+        const double seen = static_cast<double>(images_on_gpu_) + static_cast<double>(queue_.size() + 1) * group[0]->batch;
+        outstanding_peak_ = std::max(seen, outstanding_peak_ * 0.98);
+        if (outstanding_peak_ <= 0.6 * 4 * pipe_.max_batch) {
+          const int step = std::max(1, group[0]->batch);
+          const double per = outstanding_peak_ / (2.0 * static_cast<double>(instances_.size()));
+          int c = static_cast<int>((static_cast<long long>(per + step - 1e-9) / step)) * step;
+          cap = std::min(pipe_.max_batch, std::max(step, c));
+        }
+      }
+      while (total < cap) {
+        if (!queue_.empty()) {
+          if (total + queue_.front()->batch > cap) break;  // stays first in line for the next batch
+          total += queue_.front()->batch;
+          group.push_back(std::move(queue_.front()));
+          queue_.pop_front();
+          continue;
+        }
+        if (!have_slot && inflight_ < cap_) {
+          ++inflight_;
+          have_slot = true;
+        }
+        if (!have_slot) {
+          // GPU full: wait for a slot, absorbing arrivals meanwhile
+          WaitFor(cv_, lk, us(500), [this] { return stop_ || !queue_.empty() || inflight_ < cap_; });
+          if (stop_ && queue_.empty() && inflight_ >= cap_) continue;  // keeps waiting for the slot
+          continue;
+        }
+        const uint64_t now_ns = NowNs();
+        if (group.back()->gap_ns < static_cast<uint64_t>(pipe_.burst_gap_us) * 1000ull ||
+            (group.size() < last_done_requests_ && now_ns - last_done_ns_ < static_cast<uint64_t>(pipe_.burst_gap_us) * 1000ull))
+          deadline = std::max(deadline, t_first + us(pipe_.burst_window_us));
+        const bool filling = pipe_.fill_window_us > 0 && MinBusy() >= 1;
+        const auto limit = filling ? std::max(deadline, t_first + us(pipe_.fill_window_us)) : deadline;
+        const auto now = Clock::now();
+        if (now >= limit || stop_) break;
+        auto wait = limit - now;
+        if (filling && wait > us(200)) wait = us(200);
+        const bool woke = WaitFor(cv_, lk, wait, [this] { return stop_ || !queue_.empty(); });
+        if (!woke && !filling) break;
+      }
+      while (!have_slot) {
+        if (inflight_ < cap_) {
+          ++inflight_;
+          have_slot = true;
+          break;
+        }
+        WaitFor(cv_, lk, us(500), [this] { return inflight_ < cap_; });
+      }
+      running_ += group.size();
+      // two idle instances: a batch of several requests runs faster as two halves side by side
+      std::vector<std::unique_ptr<GraphJob>> second;
+      int second_total = 0;
+      if (instances_.size() >= 2 && group.size() >= 2 && total >= pipe_.split_min_batch && inflight_ < cap_) {
+        bool idle = true;
+        for (const auto& inst : instances_) idle = idle && inst->busy == 0;
+        if (idle) {
+          int acc = 0;
+          size_t keep = 0;
+          while (keep < group.size() && !(acc >= (total + 1) / 2 && keep > 0)) acc += group[keep++]->batch;
+          if (keep < group.size()) {
+            ++inflight_;
+            for (size_t i = keep; i < group.size(); ++i) second.push_back(std::move(group[i]));
+            group.resize(keep);
+            second_total = total - acc;
+            total = acc;
+          }
+        }
+      }
+      Launch(&lk, std::move(group), total);
+      if (!second.empty()) Launch(&lk, std::move(second), second_total);
+    }
+  }
+
+  // Called with the lock held; releases it around the HIP calls.
+  void Launch(std::unique_lock<std::mutex>* lk, std::vector<std::unique_ptr<GraphJob>>&& group, int total) {
+    int inst_index = 0;
+    for (size_t i = 1; i < instances_.size(); ++i)
+      if (instances_[i]->busy < instances_[static_cast<size_t>(inst_index)]->busy) inst_index = static_cast<int>(i);
+    Instance& inst = *instances_[static_cast<size_t>(inst_index)];
+    ++inst.busy;
+    void* event = nullptr;
+    if (!inst.free_events.empty()) {
+      event = inst.free_events.back();
+      inst.free_events.pop_back();
+    }
+    lk->unlock();
+    const uint64_t t_exec = NowNs();
+    const GraphPipe::Graph* graph = nullptr;
+    for (const auto& g : inst.graphs)
+      if (g.batch >= total) {
+        graph = &g;
+        break;
+      }
+    int rc = graph != nullptr ? 0 : -1;
+    if (rc == 0 && event == nullptr) rc = pipe_.event_create(&event);
+    if (rc == 0) {
+      const size_t n = group.size();
+      srcs_.resize(n);
+      dsts_.resize(n);
+      bytes_.resize(n);
+      uint64_t row = 0;
+      for (size_t i = 0; i < n; ++i) {
+        srcs_[i] = reinterpret_cast<const void*>(static_cast<uintptr_t>(group[i]->in_ptr));
+        dsts_[i] = reinterpret_cast<void*>(static_cast<uintptr_t>(graph->in_ptr + row * pipe_.in_row_bytes));
+        bytes_[i] = static_cast<uint64_t>(group[i]->batch) * pipe_.in_row_bytes;
+        row += static_cast<uint64_t>(group[i]->batch);
+      }
+      rc = pipe_.batched_copy(srcs_.data(), dsts_.data(), bytes_.data(), static_cast<int>(n), inst.stream);
+      if (rc == 0) rc = pipe_.graph_launch(graph->exec, inst.stream);
+      if (rc == 0) {
+        row = 0;
+        for (size_t i = 0; i < n; ++i) {
+          srcs_[i] = reinterpret_cast<const void*>(static_cast<uintptr_t>(graph->out_ptr + row * pipe_.out_row_bytes));
+          dsts_[i] = reinterpret_cast<void*>(static_cast<uintptr_t>(group[i]->out_ptr));
+          bytes_[i] = static_cast<uint64_t>(group[i]->batch) * pipe_.out_row_bytes;
+          row += static_cast<uint64_t>(group[i]->batch);
+        }
+        rc = pipe_.batched_copy(srcs_.data(), dsts_.data(), bytes_.data(), static_cast<int>(n), inst.stream);
+      }
+      if (rc == 0) rc = pipe_.event_record(event, inst.stream);
+    }
+    const uint64_t t_enq = NowNs();
+    if (rc != 0) {
+      // nothing (or not everything) was enqueued: whatever was runs to its end before the regions go back,
+      // then the requests take the general path
+      if (event != nullptr && pipe_.event_record(event, inst.stream) == 0) pipe_.event_sync(event);
+      for (auto& job : group) owner_->FinishGraphJob(job.get(), false, 0, 0, 0, false);
+      lk->lock();
+      if (event != nullptr) inst.free_events.push_back(event);
+      --inst.busy;
+      --inflight_;
+      running_ -= group.size();
+      if (queue_.empty() && running_ == 0) idle_cv_.notify_all();
+      return;
+    }
+    lk->lock();
+    images_on_gpu_ += total;
+    ++counters_.batches;
+    counters_.requests += group.size();
+    counters_.images += static_cast<uint64_t>(total);
+    counters_.padded_images += static_cast<uint64_t>(graph->batch - total);
+    Launched l;
+    l.event = event;
+    l.jobs = std::move(group);
+    l.total = total;
+    l.t_exec = t_exec;
+    l.t_enq = t_enq;
+    inst.launched.push_back(std::move(l));
+    inst.cv.notify_one();
+  }
+
+  void CompleteLoop(int index) {
+    if (pipe_.set_device != nullptr) pipe_.set_device(pipe_.device);
+    Instance& inst = *instances_[static_cast<size_t>(index)];
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      inst.cv.wait(lk, [&] { return completers_stop_ || !inst.launched.empty(); });
+      if (inst.launched.empty()) return;
+      Launched l = std::move(inst.launched.front());
+      inst.launched.pop_front();
+      lk.unlock();
+      const int rc = pipe_.event_sync(l.event);
+      const uint64_t t_done = NowNs();
+      lk.lock();
+      --inst.busy;
+      --inflight_;
+      images_on_gpu_ -= l.total;
+      last_done_ns_ = t_done;
+      last_done_requests_ = l.jobs.size();
+      inst.free_events.push_back(l.event);
+      lk.unlock();
+      cv_.notify_all();  // a slot is free
+      bool first = true;
+      for (auto& job : l.jobs) {
+        owner_->FinishGraphJob(job.get(), rc == 0, l.t_exec, l.t_enq, t_done, first);
+        first = false;
+      }
+      lk.lock();
+      running_ -= l.jobs.size();
+      if (queue_.empty() && running_ == 0) idle_cv_.notify_all();
+    }
+  }
+
+  NativeExecutor* owner_;
+  GraphPipe pipe_;
+  std::vector<std::unique_ptr<Instance>> instances_;
+  std::mutex mu_;
+  std::condition_variable cv_, idle_cv_;
+  std::deque<std::unique_ptr<GraphJob>> queue_;
+  bool stop_ = false, completers_stop_ = false;
+  int inflight_ = 0, cap_ = 2;
+  long long images_on_gpu_ = 0;
+  double outstanding_peak_ = 0;
+  uint64_t last_arrival_ns_ = 0, last_done_ns_ = 0;
+  size_t last_done_requests_ = 1, running_ = 0;
+  GraphCounters counters_;
+  std::thread batch_thread_;
+  std::vector<const void*> srcs_;  // scratch of the batch thread
+  std::vector<void*> dsts_;
+  std::vector<uint64_t> bytes_;
+};
+
+std::shared_ptr<NativeExecutor::GraphRunner> NativeExecutor::FindRunner(const std::string& model) {
+  std::shared_lock<std::shared_mutex> lk(mu_);
+  auto it = runners_.find(model);
+  return it == runners_.end() ? nullptr : it->second;
+}
+
+Error NativeExecutor::EnableGraphModel(const std::string& model, const GraphPipe& pipe) {
+  if (pipe.graph_launch == nullptr || pipe.event_create == nullptr || pipe.event_record == nullptr ||
+      pipe.event_sync == nullptr || pipe.event_destroy == nullptr || pipe.batched_copy == nullptr)
+    return Error("graph model '" + model + "': incomplete set of entry points");
+  if (pipe.streams.empty() || pipe.graphs.empty() || pipe.in_row_bytes == 0 || pipe.out_row_bytes == 0 || pipe.max_batch < 1)
+    return Error("graph model '" + model + "': incomplete description");
+  std::vector<int> largest(pipe.streams.size(), 0);
+  for (const auto& g : pipe.graphs) {
+    if (g.instance < 0 || static_cast<size_t>(g.instance) >= pipe.streams.size() || g.batch < 1 || g.exec == nullptr ||
+        g.in_ptr == 0 || g.out_ptr == 0)
+      return Error("graph model '" + model + "': invalid graph entry");
+    largest[static_cast<size_t>(g.instance)] = std::max(largest[static_cast<size_t>(g.instance)], g.batch);
+  }
+  for (int b : largest)
+    if (b < pipe.max_batch) return Error("graph model '" + model + "': every instance needs a graph for the largest batch");
+  {
+    std::shared_ptr<Model> m = FindModel(model, std::string());
+    if (!m || m->kernel != kGraph) return Error("graph model '" + model + "' is not registered with the graph kernel");
+  }
+  DisableGraphModel(model);
+  auto runner = std::make_shared<GraphRunner>(this, pipe);
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  runners_[model] = std::move(runner);
+  return Error::Success();
+}
+
+void NativeExecutor::DisableGraphModel(const std::string& model) {
+  std::vector<std::shared_ptr<GraphRunner>> going;
+  {
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    if (model.empty()) {
+      for (auto& kv : runners_) going.push_back(kv.second);
+      runners_.clear();
+    } else {
+      auto it = runners_.find(model);
+      if (it != runners_.end()) {
+        going.push_back(it->second);
+        runners_.erase(it);
+      }
+    }
+  }
+  for (auto& r : going) r->Stop();  // requests that found the runner a moment ago are answered or handed back
+}
+
+void NativeExecutor::QuiesceGraphModels() {
+  std::vector<std::shared_ptr<GraphRunner>> all;
+  {
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    for (auto& kv : runners_) all.push_back(kv.second);
+  }
+  for (auto& r : all) r->WaitIdle();
+}
+
+bool NativeExecutor::GraphStats(const std::string& model, GraphCounters* out) {
+  std::shared_ptr<GraphRunner> r = FindRunner(model);
+  if (!r) return false;
+  r->Counters(out);
+  return true;
+}
+
+// Validates a request for a graph model as far as the general path would before it queues the request,
+// and takes the leases on its regions.  False = not ours (the general path serves it, or words the error).
+bool NativeExecutor::PrepareGraphJob(Request* req, const std::shared_ptr<Model>& model, const GraphRunner& runner,
+                                     GraphJob* job) {
+  const ModelSpec& spec = model->spec;
+  const GraphPipe& pipe = runner.pipe();
+  if (req->has_sequence || req->inputs.size() != 1 || req->outputs.size() != 1) return false;  // the output must name its region
+  const Request::Input& in = req->inputs[0];
+  const Request::Output& out = req->outputs[0];
+  const TensorSpec& ts = spec.inputs[0];
+  if (in.name != ts.name || in.datatype != ts.datatype || !in.shm.set || in.has_data) return false;
+  if (out.name != spec.outputs[0].name || !out.shm.set) return false;
+  if (in.shape.size() != ts.dims.size() + 1) return false;
+  for (size_t d = 0; d < ts.dims.size(); ++d)
+    if (in.shape[d + 1] != ts.dims[d]) return false;
+  const int64_t batch = in.shape[0];
+  if (batch < 1 || batch > spec.max_batch || batch > pipe.max_batch) return false;
+  const uint64_t in_need = static_cast<uint64_t>(batch) * pipe.in_row_bytes;
+  const uint64_t out_need = static_cast<uint64_t>(batch) * pipe.out_row_bytes;
+  if (in.shm.offset < 0 || out.shm.offset < 0 || in.shm.size < 0 || out.shm.size < 0) return false;
+  if (static_cast<uint64_t>(in.shm.size) < in_need || static_cast<uint64_t>(out.shm.size) < out_need) return false;
+  {
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    auto lease = [&](const ShmRef& ref, uint64_t need, uint64_t* address) {
+      auto it = device_regions_.find(ref.region);
+      if (it == device_regions_.end() || it->second->device != pipe.device) return false;
+      const DeviceRegion& r = *it->second;
+      const uint64_t off = static_cast<uint64_t>(ref.offset), size = static_cast<uint64_t>(ref.size);
+      if (off + size < off || off + size > r.size || off + need > r.size) return false;
+      if ((r.address + off) % 16 != 0) return false;  // odd offsets: the general path copies through an aligned buffer
+      *address = r.address + off;
+      it->second->inflight.fetch_add(1, std::memory_order_acq_rel);
+      job->leases.push_back(it->second);
+      return true;
+    };
+    if (!lease(in.shm, in_need, &job->in_ptr) || !lease(out.shm, out_need, &job->out_ptr)) {
+      for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
+      job->leases.clear();
+      return false;
+    }
+  }
+  job->batch = static_cast<int>(batch);
+  req->results.clear();
+  Result r;
+  r.name = out.name;
+  r.datatype = spec.outputs[0].datatype;
+  r.shape.push_back(batch);
+  for (int64_t d : spec.outputs[0].dims) r.shape.push_back(d);
+  r.shm = out.shm;
+  req->results.push_back(std::move(r));
+  req->version_used = spec.version;
+  return true;
+}
+
+NativeExecutor::Outcome NativeExecutor::SubmitGraph(Request* req, const std::shared_ptr<Model>& model, std::string* bytes,
+                                                    Completion done, HttpCompletion http_done) {
+  std::shared_ptr<GraphRunner> runner = FindRunner(model->spec.name);
+  auto job = std::make_unique<GraphJob>();
+  if (!runner || !PrepareGraphJob(req, model, *runner, job.get())) {
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return Outcome::kDeclined;
+  }
+  req->inputs.clear();  // pointed into the request bytes, which move now
+  job->req = std::move(*req);
+  job->model = model;
+  job->request_bytes = std::move(*bytes);
+  job->done = std::move(done);
+  job->http_done = std::move(http_done);
+  if (!runner->Submit(&job)) {  // stopping: hand the request back untouched
+    *bytes = std::move(job->request_bytes);
+    for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
+    declined_.fetch_add(1, std::memory_order_relaxed);
+    return Outcome::kDeclined;
+  }
+  return Outcome::kDeferred;
+}
+
+// One request of a launched batch: builds the answer, counts it, frees the regions, tells the caller.
+void NativeExecutor::FinishGraphJob(GraphJob* job, bool ok, uint64_t t_exec, uint64_t t_enq, uint64_t t_done, bool first) {
+  std::string payload;
+  HeaderList headers;
+  std::vector<std::string> parts;
+  if (ok) {
+    if (job->http_done) BuildHttpResponse(job->req, &job->req.results, &headers, &parts);
+    else BuildGrpcResponse(job->req, job->req.results, -1, &payload);
+    const uint64_t now = NowNs();
+    std::lock_guard<std::mutex> lk(job->model->stats_mu);
+    Stats& s = job->model->stats;
+    if (first) ++s.requests;  // executions: one per launched batch
+    s.inferences += static_cast<uint64_t>(job->batch);
+    s.queue_ns += t_exec - job->req.t_arrive;
+    s.last_ms = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::milliseconds>(
+                                          std::chrono::system_clock::now().time_since_epoch()).count());
+    BatchStats& bs = s.by_batch[job->batch];
+    ++bs.count;
+    bs.input_ns += t_enq - t_exec;
+    bs.infer_ns += t_done - t_enq;
+    bs.output_ns += now - t_done;
+    handled_.fetch_add(1, std::memory_order_relaxed);
+  } else {
+    payload = std::move(job->request_bytes);
+    declined_.fetch_add(1, std::memory_order_relaxed);
+  }
+  // the regions are free again before the caller hears about it: it may unregister them right away
+  for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
+  job->leases.clear();
+  if (job->http_done) {
+    if (!ok) parts.assign(1, std::move(payload));
+    job->http_done(ok, std::move(headers), std::move(parts));
+  } else {
+    job->done(ok, std::move(payload));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1311,7 +1843,9 @@ bool NativeExecutor::TryHttp(const std::string& model_name, const std::string& v
 
 bool NativeExecutor::Defers(const std::string& model) {
   std::shared_ptr<Model> m = FindModel(model, std::string());
-  return m && (m->kernel == kBytesAddSub || m->kernel == kBytesIdentity) && pipe_on_.load(std::memory_order_acquire);
+  if (!m) return false;
+  if (m->kernel == kGraph) return FindRunner(model) != nullptr;
+  return (m->kernel == kBytesAddSub || m->kernel == kBytesIdentity) && pipe_on_.load(std::memory_order_acquire);
 }
 
 NativeExecutor::Outcome NativeExecutor::TryHttpAsync(const std::string& model_name, const std::string& version,
@@ -1321,6 +1855,7 @@ NativeExecutor::Outcome NativeExecutor::TryHttpAsync(const std::string& model_na
   Request req;
   std::shared_ptr<Model> model;
   if (!ParseHttp(model_name, version, *body, header_length, &req, &model)) return Outcome::kDeclined;
+  if (model->kernel == kGraph) return SubmitGraph(&req, model, body, Completion(), std::move(done));
   if (model->kernel == kBytesAddSub || model->kernel == kBytesIdentity) {
     auto job = std::make_unique<DeviceJob>();
     if (!pipe_on_.load(std::memory_order_acquire) || !PrepareDeviceJob(&req, model, job.get())) {

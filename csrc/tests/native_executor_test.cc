@@ -5,6 +5,9 @@
 // a declined one is fine (the model or a region was just away), a wrong one is not.
 // A second part drives the device BYTES path (deferred answers from the executor's batch thread)
 // against a host stand-in for the HIP pipeline while the region is unregistered and re-registered.
+// A third part serves a "graph" model (requests merged along the batch axis, padded up to the next captured
+// size, gathered / launched / scattered on instance streams and answered by completer threads) against
+// host stand-ins for streams, events, graphs and the batched copy.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -12,6 +15,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <cstring>
@@ -430,6 +435,328 @@ void DeviceBytesPath() {
   if (answered.load() == 0 || refused.load() == 0) Fail("device bytes: nothing was answered or nothing refused");
 }
 
+
+// ---- host stand-ins for the HIP side of a graph model --------------------------------------------------
+// A stream is a FIFO of closures run by a worker thread, an event a flag the FIFO sets, a graph a function
+// over its two static buffers: out[row] = {sum of the row's 4 inputs + 1, 2 x first input}.
+struct FakeStream {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> work;
+  bool stop = false;
+  std::thread th;
+  FakeStream() : th([this] { Run(); }) {}
+  ~FakeStream() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    th.join();
+  }
+  void Push(std::function<void()> fn) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      work.push_back(std::move(fn));
+    }
+    cv.notify_all();
+  }
+  void Run() {
+    for (;;) {
+      std::function<void()> fn;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return stop || !work.empty(); });
+        if (work.empty()) return;
+        fn = std::move(work.front());
+        work.pop_front();
+      }
+      fn();
+    }
+  }
+};
+struct FakeEvent {
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t recorded = 0, reached = 0;
+};
+struct FakeGraph {
+  int batch = 0;
+  std::vector<float> in, out;  // [batch][4], [batch][2]
+  std::atomic<long> launches{0};
+};
+std::atomic<int> g_fail_launches{0};  // > 0: the next graph launches report an error
+
+int FakeGraphLaunch(void* exec, void* stream) {
+  if (g_fail_launches.load() > 0 && g_fail_launches.fetch_sub(1) > 0) return -5;
+  auto* g = static_cast<FakeGraph*>(exec);
+  static_cast<FakeStream*>(stream)->Push([g] {
+    std::this_thread::sleep_for(std::chrono::microseconds(40));  // a forward pass takes a while
+    for (int r = 0; r < g->batch; ++r) {
+      const float* x = &g->in[static_cast<size_t>(r) * 4];
+      g->out[static_cast<size_t>(r) * 2] = x[0] + x[1] + x[2] + x[3] + 1.0f;
+      g->out[static_cast<size_t>(r) * 2 + 1] = 2.0f * x[0];
+    }
+    ++g->launches;
+  });
+  return 0;
+}
+int FakeEventCreate(void** event) {
+  *event = new FakeEvent();
+  return 0;
+}
+int FakeEventRecord(void* event, void* stream) {
+  auto* e = static_cast<FakeEvent*>(event);
+  uint64_t ticket;
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    ticket = ++e->recorded;
+  }
+  static_cast<FakeStream*>(stream)->Push([e, ticket] {
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->reached = ticket;
+    e->cv.notify_all();
+  });
+  return 0;
+}
+int FakeEventSync(void* event) {
+  auto* e = static_cast<FakeEvent*>(event);
+  std::unique_lock<std::mutex> lk(e->mu);
+  const uint64_t want = e->recorded;
+  e->cv.wait(lk, [&] { return e->reached >= want; });
+  return 0;
+}
+int FakeEventDestroy(void* event) {
+  delete static_cast<FakeEvent*>(event);
+  return 0;
+}
+int FakeBatchedCopy(const void* const* srcs, void* const* dsts, const uint64_t* bytes, int n, void* stream) {
+  struct Triple {
+    const void* src;
+    void* dst;
+    uint64_t bytes;
+  };
+  std::vector<Triple> items;
+  for (int i = 0; i < n; ++i) items.push_back({srcs[i], dsts[i], bytes[i]});  // the caller reuses its arrays
+  static_cast<FakeStream*>(stream)->Push([items] {
+    for (const auto& t : items) std::memcpy(t.dst, t.src, t.bytes);
+  });
+  return 0;
+}
+
+std::string GraphRequest(const std::string& region, int batch, int64_t in_off, int64_t out_off, int64_t out_size,
+                         bool name_output = true) {
+  std::string out;
+  pb::Writer w(&out);
+  w.String(1, "classifier");
+  w.String(3, "g-7");
+  std::string t, shape;
+  pb::Writer tw(&t), sw(&shape);
+  tw.String(1, "input");
+  tw.String(2, "FP32");
+  sw.Varint(static_cast<uint64_t>(batch));
+  sw.Varint(4);
+  tw.Message(3, shape);
+  Param(&tw, 4, "shared_memory_region", &region, 0);
+  Param(&tw, 4, "shared_memory_byte_size", nullptr, static_cast<int64_t>(batch) * 16);
+  if (in_off) Param(&tw, 4, "shared_memory_offset", nullptr, in_off);
+  w.Message(5, t);
+  if (name_output) {
+    std::string o;
+    pb::Writer ow(&o);
+    ow.String(1, "output");
+    Param(&ow, 2, "shared_memory_region", &region, 0);
+    Param(&ow, 2, "shared_memory_byte_size", nullptr, out_size);
+    Param(&ow, 2, "shared_memory_offset", nullptr, out_off);
+    w.Message(6, o);
+  }
+  return out;
+}
+
+// Worker threads keep requests of batch 1..8 in flight against a model with graphs for 1, 2, 4, 8, 16 on two
+// instances while the region is unregistered and re-registered; every answer is checked row by row, every
+// refusal hands the request back, statistics count requests, batches and padding.
+void GraphPath() {
+  NativeExecutor ex;
+  NativeExecutor::ModelSpec m;
+  m.name = "classifier";
+  m.version = "1";
+  m.max_batch = 16;
+  m.kernel = "graph";
+  m.inputs = {{"input", "FP32", {4}}};
+  m.outputs = {{"output", "FP32", {2}}};
+  if (!ex.SetModel(m).IsOk()) Fail("graph: registering the model");
+  constexpr int kThreads = 6;
+  constexpr size_t kSlot = 512;  // inputs at 0 (8 x 16 bytes), outputs at 256 (8 x 8 bytes)
+  std::vector<uint8_t> memory(kThreads * kSlot + 64);
+  uint8_t* base = memory.data() + (16 - reinterpret_cast<uintptr_t>(memory.data()) % 16) % 16;
+  std::string probe = GraphRequest("dev", 2, 0, 256, 64), response;
+  if (ex.TryGrpcAsync(&probe, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+    Fail("graph: accepted without graphs");
+  FakeStream streams[2];
+  std::vector<std::unique_ptr<FakeGraph>> graphs;
+  NativeExecutor::GraphPipe pipe;
+  pipe.graph_launch = FakeGraphLaunch;
+  pipe.event_create = FakeEventCreate;
+  pipe.event_record = FakeEventRecord;
+  pipe.event_sync = FakeEventSync;
+  pipe.event_destroy = FakeEventDestroy;
+  pipe.batched_copy = FakeBatchedCopy;
+  pipe.streams = {&streams[0], &streams[1]};
+  pipe.in_row_bytes = 16;
+  pipe.out_row_bytes = 8;
+  pipe.max_batch = 16;
+  pipe.fill_window_us = 200;
+  pipe.split_min_batch = 4;
+  for (int inst = 0; inst < 2; ++inst)
+    for (int b : {1, 2, 4, 8, 16}) {
+      graphs.emplace_back(new FakeGraph());
+      FakeGraph* g = graphs.back().get();
+      g->batch = b;
+      g->in.assign(static_cast<size_t>(b) * 4, -1000.f);
+      g->out.assign(static_cast<size_t>(b) * 2, 0.f);
+      NativeExecutor::GraphPipe::Graph e;
+      e.instance = inst;
+      e.batch = b;
+      e.exec = g;
+      e.in_ptr = reinterpret_cast<uint64_t>(g->in.data());
+      e.out_ptr = reinterpret_cast<uint64_t>(g->out.data());
+      pipe.graphs.push_back(e);
+    }
+  {
+    NativeExecutor::GraphPipe small = pipe;
+    small.graphs.pop_back();  // instance 1 loses its largest graph
+    if (ex.EnableGraphModel("classifier", small).IsOk()) Fail("graph: accepted an instance without a graph for the largest batch");
+    if (ex.EnableGraphModel("nobody", pipe).IsOk()) Fail("graph: accepted a model that is not registered");
+  }
+  if (!ex.EnableGraphModel("classifier", pipe).IsOk()) Fail("graph: enabling");
+  if (!ex.Defers("classifier")) Fail("graph: the model is not reported as deferring");
+  if (ex.TryGrpcAsync(&probe, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+    Fail("graph: accepted a request for a region that is not registered");
+  if (!ex.RegisterDeviceRegion("dev", reinterpret_cast<uint64_t>(base), kThreads * kSlot, 0).IsOk())
+    Fail("graph: registering the region");
+  {
+    std::string no_out = GraphRequest("dev", 2, 0, 256, 64, false);
+    if (ex.TryGrpcAsync(&no_out, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+      Fail("graph: an output without a region must take the general path");
+    std::string tiny = GraphRequest("dev", 4, 0, 256, 16);
+    if (ex.TryGrpcAsync(&tiny, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+      Fail("graph: an output range that cannot hold the result must take the general path");
+    std::string odd = GraphRequest("dev", 1, 4, 256, 64);
+    if (ex.TryGrpcAsync(&odd, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+      Fail("graph: a misaligned input must take the general path");
+    std::string big = GraphRequest("dev", 17, 0, 256, 4096);
+    if (ex.TryGrpcAsync(&big, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+      Fail("graph: a batch beyond the model's limit must take the general path");
+  }
+  std::atomic<bool> stop{false};
+  std::atomic<long> answered{0}, refused{0}, declined{0}, images{0};
+  std::vector<std::thread> workers;
+  for (int t = 0; t < kThreads; ++t) {
+    workers.emplace_back([&, t] {
+      uint8_t* slot = base + static_cast<size_t>(t) * kSlot;
+      std::mutex mu;
+      std::condition_variable cv;
+      std::string resp;
+      for (int round = 0; !stop.load(); ++round) {
+        const int batch = 1 + (round * 5 + t) % 8;
+        float in[8 * 4];
+        for (int i = 0; i < batch * 4; ++i) in[i] = static_cast<float>((round * 131 + i * 7 + t * 1009) % 4001) - 2000.f;
+        std::memcpy(slot, in, static_cast<size_t>(batch) * 16);
+        std::memset(slot + 256, 0xEE, 64);
+        std::string request = GraphRequest("dev", batch, static_cast<int64_t>(t) * kSlot, static_cast<int64_t>(t) * kSlot + 256, 64);
+        const std::string copy = request;
+        bool done = false, ok = false;
+        std::string payload;
+        const auto outcome = ex.TryGrpcAsync(&request, &resp, [&](bool good, std::string&& p) {
+          std::lock_guard<std::mutex> lk(mu);
+          ok = good;
+          payload = std::move(p);
+          done = true;
+          cv.notify_one();
+        });
+        if (outcome == NativeExecutor::Outcome::kDeclined) {
+          if (request != copy) Fail("graph: a declined request was consumed");
+          ++declined;
+          continue;
+        }
+        if (outcome != NativeExecutor::Outcome::kDeferred) {
+          Fail("graph: answered inline");
+          continue;
+        }
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return done; });
+        }
+        if (!ok) {
+          if (payload != copy) Fail("graph: a refusal without the request");
+          ++refused;
+          continue;
+        }
+        float out[16];
+        std::memcpy(out, slot + 256, static_cast<size_t>(batch) * 8);
+        for (int r = 0; r < batch; ++r) {
+          const float* x = in + r * 4;
+          if (out[2 * r] != x[0] + x[1] + x[2] + x[3] + 1.0f || out[2 * r + 1] != 2.0f * x[0]) {
+            Fail("graph: wrong row (merged batches must keep every request's rows apart)");
+            break;
+          }
+        }
+        if (payload.find("classifier") == std::string::npos || payload.find("output") == std::string::npos ||
+            payload.find("g-7") == std::string::npos)
+          Fail("graph: response without its model, output or id");
+        ++answered;
+        images += batch;
+      }
+    });
+  }
+  std::thread churn([&] {
+    int round = 0;
+    while (!stop.load()) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(4));
+      if (!ex.UnregisterDeviceRegion("dev", 5000)) Fail("graph: the region never became idle");
+      std::this_thread::sleep_for(std::chrono::microseconds(300));
+      if (!ex.RegisterDeviceRegion("dev", reinterpret_cast<uint64_t>(base), kThreads * kSlot, 0).IsOk())
+        Fail("graph: registering the region again");
+      if (++round % 16 == 0) g_fail_launches.store(2);  // two launches fail: their requests come back
+    }
+  });
+  std::this_thread::sleep_for(std::chrono::milliseconds(1500));
+  stop.store(true);
+  for (auto& w : workers) w.join();
+  churn.join();
+  ex.Quiesce();
+  NativeExecutor::GraphCounters counters;
+  if (!ex.GraphStats("classifier", &counters)) Fail("graph: no counters");
+  NativeExecutor::Stats st;
+  if (!ex.TakeStats("classifier", &st) || st.inferences != static_cast<uint64_t>(images.load()))
+    Fail("graph: statistics do not match the answered requests");
+  if (counters.requests < static_cast<uint64_t>(answered.load()) || counters.batches == 0 || counters.batches > counters.requests)
+    Fail("graph: batch counters out of range");
+  long launches = 0;
+  for (const auto& g : graphs) launches += g->launches.load();
+  if (static_cast<uint64_t>(launches) != counters.batches) Fail("graph: launches counted do not match the graphs' own count");
+  // a request queued while the model goes away is answered or handed back, never dropped
+  {
+    std::atomic<int> verdicts{0};
+    std::memset(base, 0, 64);
+    for (int i = 0; i < 20; ++i) {
+      std::string request = GraphRequest("dev", 1, 0, 256, 64);
+      if (ex.TryGrpcAsync(&request, &response, [&](bool, std::string&&) { ++verdicts; }) != NativeExecutor::Outcome::kDeferred)
+        ++verdicts;
+    }
+    ex.DisableGraphModel("classifier");
+    if (verdicts.load() != 20) Fail("graph: requests were dropped when the model was disabled");
+  }
+  std::string late = GraphRequest("dev", 1, 0, 256, 64);
+  if (ex.TryGrpcAsync(&late, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+    Fail("graph: accepted after the model was disabled");
+  std::cout << "graph model: answered " << answered.load() << " requests (" << images.load() << " batch entries) in "
+            << counters.batches << " batches, " << counters.padded_images << " padded rows, refused " << refused.load()
+            << ", declined " << declined.load() << std::endl;
+  if (answered.load() == 0 || counters.padded_images == 0 || refused.load() == 0) Fail("graph: nothing answered, padded or refused");
+}
+
 // Stateful kernel: threads run whole sequences through the gRPC path while another one walks sequences of its
 // own through SequenceStep (what the Python core does for requests that took the general path).
 std::string SequenceRequest(const char* model, int32_t value, uint64_t id, bool start, bool end) {
@@ -702,6 +1029,7 @@ int main() {
   shm_unlink(key);
   DeviceBytesPath();
   SequencePath();
+  GraphPath();
   std::cout << "answered " << answered.load() << ", declined " << declined.load() << ", statistics collected for "
             << collected.load() << ", failures " << g_failures.load() << std::endl;
   if (g_failures.load() != 0 || answered.load() == 0) return 1;

@@ -41,6 +41,50 @@ def test_fused_forward_matches_library_and_fp32(model, batch):
     assert (fused.argmax(1) == ref.argmax(1)).float().mean().item() >= 0.75
 
 
+@pytest.mark.parametrize("batch", [88, 128])
+@pytest.mark.parametrize("tuning", ["1", "0"])
+def test_large_batches_tuned_and_untuned_against_fp32(batch, tuning, monkeypatch):
+    """The sizes the serving headline replays (merged batches of 88 .. 128 on the tuned dispatch table: 256-wide
+    tiles on 16 wavefronts, fused and attached blocks, the row-organised stage-1 kernel) and the same sizes
+    with the table off, as captured graphs on BOTH execution instances at once, against the fp32 network:
+    relative error below 2e-2, within 2x of the library forward, and the two instances bit-identical."""
+    import torch
+
+    from triton_client_amd.models import MODEL_ZOO
+    from triton_client_amd.ops import conv
+
+    monkeypatch.setenv("TCA_CONV_TUNING", tuning)
+    monkeypatch.setattr(conv, "_tuning", None)
+    m = MODEL_ZOO["resnet50"]()
+    m.load(0)
+    try:
+        gen = torch.Generator(device="cuda").manual_seed(batch)
+        x = torch.randn(batch, 3, 224, 224, device="cuda", generator=gen).half()
+        outs = [torch.empty(batch, 1000, device="cuda", dtype=torch.float32) for _ in range(m.instance_count)]
+        for _ in range(2):  # capture, then replay: both instances enqueue before either is waited for
+            for inst, out in enumerate(outs):
+                m.run(x, out, inst, stable=True)
+        for inst in range(m.instance_count):
+            m.stream_of(inst).synchronize()
+        with torch.no_grad(), torch.cuda.stream(m.stream):
+            m.fused = False
+            plain = m._forward_eager(x)
+            m.fused = True
+            ref = m._net.float()(x.float().contiguous(memory_format=torch.channels_last))
+            m._net.half()
+        m.stream.synchronize()
+        scale = ref.abs().max().item()
+        err = (outs[0] - ref).abs().max().item() / scale
+        err_plain = (plain - ref).abs().max().item() / scale
+        assert err < 2e-2 and err < 2.0 * err_plain + 2e-3, (err, err_plain)
+        assert (outs[0].argmax(1) == ref.argmax(1)).float().mean().item() >= 0.9
+        for other in outs[1:]:
+            assert torch.equal(other, outs[0])
+    finally:
+        m.unload()
+        monkeypatch.setattr(conv, "_tuning", None)
+
+
 def test_graph_replay_equals_eager(model):
     import torch
 

@@ -38,6 +38,14 @@ def _check(line, gpus, steps, warmup):
     for key in ("wire", "system_shm"):
         assert line["extra"][key]["infer_per_sec"] > 0
         assert line["extra"][key]["requests"] == 128 * gpus
+    # the concurrency sweep over HIP shared memory and the content check against a direct forward
+    sweep = line["extra"]["sweep"]
+    assert [row["concurrency_per_gpu"] for row in sweep] == [1, 16]
+    for row in sweep:
+        assert row["infer_per_sec"] > 0 and row["p50_latency_us"] <= row["p99_latency_us"] and row["window_s"] > 0.2
+    check = line["extra"]["check"]
+    assert check["ok"] is True, check
+    assert check["max_abs_err"] < 0.05 * check["logit_scale"] and check["min_distance_between_images"] > 4 * check["max_abs_err"]
     # ... and so are the other configurations of the benchmark set, summed over the ranks
     secondary = line["extra"]["secondary"]
     assert "error" not in secondary, secondary
@@ -49,7 +57,8 @@ def _check(line, gpus, steps, warmup):
 def test_single_rank_line():
     cmd = [sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--requests-per-step", "64", "--concurrency",
            "16",
-           "--extra-requests", "128"]
+           "--extra-requests", "128", "--sweep", "1,16", "--sweep-seconds", "0.4", "--image-requests", "256",
+           "--secondary-window-ms", "400"]
     done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert done.returncode == 0, done.stderr[-2000:]
     _check(_json_line(done.stdout), 1, 3, 1)
@@ -60,7 +69,8 @@ def test_two_ranks_print_one_aggregate_line():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--requests-per-step", "64", "--concurrency", "16",
-           "--extra-requests", "128"]
+           "--extra-requests", "128", "--sweep", "1,16", "--sweep-seconds", "0.4", "--image-requests", "256",
+           "--secondary-window-ms", "400"]
     done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
     assert done.returncode == 0, done.stderr[-2000:]
     _check(_json_line(done.stdout), 2, 3, 1)
@@ -72,7 +82,8 @@ def test_gpus_flag_alone_starts_the_ranks():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--requests-per-step", "64",
-           "--concurrency", "16", "--extra-requests", "128"]
+           "--concurrency", "16", "--extra-requests", "128", "--sweep", "1,16", "--sweep-seconds", "0.4",
+           "--image-requests", "256", "--secondary-window-ms", "400"]
     done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
     assert done.returncode == 0, done.stderr[-2000:]
     line = _json_line(done.stdout)

@@ -28,6 +28,7 @@ from .vision import ResNet50
 @register
 class ResNet50Sharded(ResNet50):
     name = "resnet50_sharded"
+    native_kernel = None  # one forward = a step of the whole replica group, driven from Python
     autoload = False  # starts replica processes: only loaded when asked for by name
     inputs = [TensorSpec("input", "FP16", [3, 224, 224], format="FORMAT_NCHW")]
     outputs = [TensorSpec("output", "FP32", [1000], label_filename="labels.txt")]

@@ -203,6 +203,12 @@ class ResNet50(Model):
     # batch sizes whose HIP graphs are captured at load time (the batcher merges
     # concurrent requests, so totals other than the request batch show up)
     warmup_batches = (8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128)
+    # Served by the native executor from captured graphs (requests with both tensors in device shared
+    # memory never reach the interpreter): the batch sizes it holds a graph for.  A merged batch runs on
+    # the smallest graph that holds it, so every request batch size - 1 included, perf_analyzer's
+    # default - is served from graphs captured at load time and nothing is ever captured online.
+    native_kernel = "graph"
+    native_batches = (1, 2, 4, 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128)
     inputs = [TensorSpec("input", "FP16", [3, 224, 224], format="FORMAT_NCHW")]
     outputs = [TensorSpec("output", "FP32", [1000], label_filename="labels.txt")]
 
@@ -215,6 +221,8 @@ class ResNet50(Model):
         self._net = None
         self._graphs = _GraphCache(int(os.environ.get("TCA_RESNET_GRAPH_CACHE", "512")))
         self._io_buffers = {}  # (instance, batch) -> static (input, output) pair for callers without stable buffers
+        self.online_captures = 0  # graphs captured after the server finished loading the model (``warmed_up``)
+        self.warmed_up = False
         self._lock = threading.RLock()
         self._stream = None
         self.labels = [f"class_{i}" for i in range(1000)]
@@ -554,6 +562,8 @@ class ResNet50(Model):
             if graph is None:
                 graph = self._capture(x, out, stream, instance)
                 self._graphs.put(key, graph, self._retire_event)
+                if self.warmed_up:
+                    self.online_captures += 1
             with torch.cuda.stream(stream), _trace.range(f"resnet50 graph replay b={batch}"):
                 graph[0].replay()
         return out
@@ -572,6 +582,41 @@ class ResNet50(Model):
 
     def graph_count(self):
         return len(self._graphs)
+
+    def native_graph_plan(self, instances):
+        """What the native executor needs to serve this model by itself: for every execution instance and
+        every size in ``native_batches`` a captured graph over static buffers of its own (the dynamic batcher
+        of the general path keeps its own, so both may enqueue on the instances' streams at any time), as
+        ``(instance, batch, hipGraphExec_t, input address, output address)``, plus the stream handles and the
+        bytes per batch entry.  ``keep`` holds the graphs and buffers alive."""
+        torch = self._torch
+        graphs, keep = [], []
+        sizes = [b for b in self.native_batches if b <= self.max_batch_size]
+        if sizes[-1] != self.max_batch_size:
+            sizes.append(self.max_batch_size)
+        spec = self.inputs[0]
+        in_dtype = torch.float16 if spec.datatype == "FP16" else torch.float32
+        for inst in range(instances):
+            for b in sizes:
+                x = torch.zeros((b, *spec.dims), device=self._device, dtype=in_dtype)
+                out = torch.empty((b, *self.outputs[0].dims), device=self._device, dtype=torch.float32)
+                self.execute({spec.name: x, "__out__" + self.outputs[0].name: out, "__instance__": inst}, None)
+                self._streams[inst].synchronize()
+                entry = self._native_graph_entry(x, out, inst)
+                graphs.append((inst, b, int(entry[0].raw_cuda_graph_exec()), int(entry[1].data_ptr()),
+                               int(out.data_ptr())))
+                keep.append((entry, x, out))
+        return {"graphs": graphs, "keep": keep, "streams": [int(s.cuda_stream) for s in self._streams[:instances]],
+                "in_row_bytes": int(keep[0][0][1][0].numel() * keep[0][0][1].element_size()),
+                "out_row_bytes": int(keep[0][2][0].numel() * 4), "max_batch": int(self.max_batch_size)}
+
+    def _native_graph_entry(self, x, out, instance):
+        """The captured graph that reads ``x`` and writes ``out`` (captured by the ``execute`` just before)."""
+        with self._lock:
+            entry = self._graphs.get((x.shape[0], x.data_ptr(), out.data_ptr(), instance))
+        if entry is None:
+            raise ModelError("no captured graph for the native executor's buffers")
+        return entry
 
     def _capture(self, x, out, stream, instance=0):
         """Capture one forward as a HIP graph.  All graphs of one execution instance allocate
@@ -623,6 +668,7 @@ class ResNet50Fp32In(ResNet50):
     when the model metadata says FP32)."""
 
     name = "resnet50_fp32"
+    native_kernel = None  # the input is converted on every call: no stable buffer for the native executor's graphs
     inputs = [TensorSpec("input", "FP32", [3, 224, 224], format="FORMAT_NCHW")]
 
 

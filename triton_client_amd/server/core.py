@@ -715,6 +715,9 @@ class InferenceCore:
             return
         model = lm.model
         kernel = getattr(model, "native_kernel", None)
+        if kernel == "graph":
+            self._sync_native_graph(lm, present)
+            return
         stateful = kernel in ("sequence", "dyna_sequence")
         eligible = present and kernel and model.device == "cpu" and not model.parameters \
             and bool(getattr(model, "sequence", False)) == stateful and (not model.decoupled or kernel == "repeat") \
@@ -732,6 +735,55 @@ class InferenceCore:
             lm.native_sequences = bool(stateful)
         except ValueError:
             executor.remove_model(model.name)
+
+    def _sync_native_graph(self, lm, present):
+        """GPU models served from captured HIP graphs (``native_kernel = "graph"``): the executor gets the
+        model's signature, a set of graphs captured over buffers of its own for every execution instance, the
+        instances' streams and the batching policy of the dynamic batcher, and from then on answers requests
+        whose tensors are in device shared memory without the interpreter (queue, leases, batch forming,
+        gather / graph launch / scatter, completion and response are all native).  Everything else - tensors
+        on the wire, classification, system shared memory, errors - keeps taking the general path."""
+        executor, model = self.native, lm.model
+        name = model.name
+        eligible = (present and lm.batcher is not None and self.devshm.native is not None and not model.parameters
+                    and getattr(model, "use_graphs", False) and len(model.inputs) == 1 and len(model.outputs) == 1
+                    and os.environ.get("TCA_NATIVE_GRAPHS", "1") != "0")
+        if not eligible:
+            executor.remove_model(name)  # stops its threads first
+            lm.native_graphs = None
+            return
+        try:
+            import ctypes
+
+            from ..ops import _device
+
+            batcher = lm.batcher
+            warmed, model.warmed_up = getattr(model, "warmed_up", False), False  # these captures are load-time ones
+            try:
+                plan = model.native_graph_plan(batcher.instances)
+            finally:
+                model.warmed_up = warmed
+            lib = _device.lib()
+            address = lambda fn: ctypes.cast(fn, ctypes.c_void_p).value  # noqa: E731
+            entry_points = tuple(address(getattr(lib, fn)) for fn in (
+                "tca_hip_graph_launch", "tca_hip_event_create", "tca_hip_event_record", "tca_hip_event_sync",
+                "tca_hip_event_destroy", "tca_hip_set_device", "tca_batched_copy_launch"))
+            executor.set_model(name, model.versions[-1], int(model.max_batch_size),
+                               [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.inputs],
+                               [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.outputs], "graph")
+            executor.enable_graph_model(
+                name, entry_points, int(self.gpu), plan["streams"], plan["graphs"], plan["in_row_bytes"],
+                plan["out_row_bytes"], plan["max_batch"], int(os.environ.get("TCA_MAX_INFLIGHT_BATCHES", 0)) or int(
+                    getattr(model, "max_inflight_batches", 2 * batcher.instances)),
+                int(batcher.fill_window_s * 1e6), int(batcher.burst_gap_s * 1e6), int(batcher.burst_window_s * 1e6),
+                int(batcher.split_min_batch), bool(batcher._adaptive_cap))
+            lm.native_graphs = plan["keep"]
+        except Exception:  # noqa: BLE001 - the general path serves the model
+            import traceback
+
+            traceback.print_exc()
+            executor.remove_model(name)
+            lm.native_graphs = None
 
     def _merge_native_stats(self, name, lm):
         executor = getattr(self, "native", None)
@@ -791,10 +843,20 @@ class InferenceCore:
             self._loaded[name] = lm
             self._failed.pop(name, None)
         self._sync_native(lm)
+        if hasattr(model, "online_captures"):
+            model.warmed_up = True  # graphs captured from here on count as online captures
         if old is not None:
             self._retire(old)
 
     def _retire(self, lm):
+        if getattr(lm, "native_graphs", None) is not None and self.native is not None:
+            # the executor replays this model's graphs: stop that before they go (unless a newer instance of
+            # the model has already replaced them there)
+            with self._lock:
+                current = self._loaded.get(lm.model.name)
+            if current is None or current is lm:
+                self.native.remove_model(lm.model.name)
+            lm.native_graphs = None
         hook = getattr(lm.model, "evict_region", None)
         if hook in self.devshm.on_close:
             self.devshm.on_close.remove(hook)
@@ -900,6 +962,26 @@ class InferenceCore:
                 lines.append(f"# HELP tca_native_{key}_total {text}")
                 lines.append(f"# TYPE tca_native_{key}_total counter")
                 lines.append(f"tca_native_{key}_total {int(counters[key])}")
+            with self._lock:
+                loaded = list(self._loaded.items())
+            graph_rows = [(name, executor.graph_stats(name)) for name, lm in loaded
+                          if getattr(lm, "native_graphs", None) is not None]
+            for key, text in (("batches", "Batches the native graph path launched"),
+                              ("requests", "Requests merged into those batches"),
+                              ("images", "Batch entries of those requests"),
+                              ("padded_images", "Rows computed beyond the merged batches (next captured size)")):
+                lines.append(f"# HELP tca_native_graph_{key}_total {text}")
+                lines.append(f"# TYPE tca_native_graph_{key}_total counter")
+                for name, row in graph_rows:
+                    if row:
+                        lines.append(f'tca_native_graph_{key}_total{{model="{name}"}} {int(row[key])}')
+        with self._lock:
+            models = list(self._loaded.items())
+        lines.append("# HELP tca_graph_captures_online_total HIP graphs captured while serving (after load-time warm-up)")
+        lines.append("# TYPE tca_graph_captures_online_total counter")
+        for name, lm in models:
+            if hasattr(lm.model, "online_captures"):
+                lines.append(f'tca_graph_captures_online_total{{model="{name}"}} {int(lm.model.online_captures)}')
         for key, text in (("hits", "Requests queued from the stored plan of their raw message"),
                           ("stored", "Request plans stored")):
             lines.append(f"# HELP tca_request_plan_{key}_total {text}")
