@@ -297,6 +297,20 @@ PyObject* DisableGraphModel(PyObject* self_obj, PyObject* args) {
   Py_RETURN_NONE;
 }
 
+PyObject* BeginCapture(PyObject* self_obj, PyObject*) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  Py_BEGIN_ALLOW_THREADS
+  (*self->ex)->BeginCapture();
+  Py_END_ALLOW_THREADS
+  Py_RETURN_NONE;
+}
+
+PyObject* EndCapture(PyObject* self_obj, PyObject*) {
+  auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
+  (*self->ex)->EndCapture();
+  Py_RETURN_NONE;
+}
+
 PyObject* GraphStats(PyObject* self_obj, PyObject* args) {
   auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
   const char* name = nullptr;
@@ -370,6 +384,9 @@ PyMethodDef kMethods[] = {
      "enable_graph_model(name, entry_points, device, streams, graphs, in_row_bytes, out_row_bytes, max_batch, max_inflight, "
      "fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap)"},
     {"disable_graph_model", DisableGraphModel, METH_VARARGS, "disable_graph_model([name]): answers what is queued and stops the threads"},
+    {"begin_capture", BeginCapture, METH_NOARGS,
+     "holds the batch threads' graph launches back (after those in progress) until end_capture(): a stream capture may run"},
+    {"end_capture", EndCapture, METH_NOARGS, "the capture is over"},
     {"graph_stats", GraphStats, METH_VARARGS, "graph_stats(name) -> batches / requests / images / padded_images, or None"},
     {"register_device_region", RegisterDeviceRegion, METH_VARARGS, "register_device_region(name, address, byte_size, device)"},
     {"unregister_device_region", UnregisterDeviceRegion, METH_VARARGS,

@@ -164,6 +164,12 @@ class NativeExecutor {
     uint64_t batches = 0, requests = 0, images = 0, padded_images = 0;
   };
   bool GraphStats(const std::string& model, GraphCounters* out);
+  // Stream capture elsewhere in the process (a model capturing one more graph) and graph launches from the
+  // batch threads here must not overlap: a launch into a capturing stream would be recorded into that graph,
+  // and under the global capture mode a launch on any stream may fail the capture.  BeginCapture waits for
+  // the enqueue sequences in progress and holds new ones back until the matching EndCapture.
+  void BeginCapture();
+  void EndCapture();
 
   // `request` = serialized ModelInferRequest; true: `response` holds the serialized ModelInferResponse.
   bool TryGrpc(const std::string& request, std::string* response);
@@ -231,6 +237,8 @@ class NativeExecutor {
   Outcome SubmitGraph(Request* req, const std::shared_ptr<Model>& model, std::string* bytes, Completion done,
                       HttpCompletion http_done);
   void QuiesceGraphModels();
+  void EnterLaunch();  // the batch threads, around every gather / launch / scatter / event sequence
+  void LeaveLaunch();
   void FinishGraphJob(GraphJob* job, bool ok, uint64_t t_exec, uint64_t t_enq, uint64_t t_done, bool first);
   bool PrepareDeviceJob(Request* req, const std::shared_ptr<Model>& model, DeviceJob* job);
   void DeviceLoop();
@@ -253,6 +261,9 @@ class NativeExecutor {
   std::map<std::string, std::shared_ptr<Region>> regions_;
   std::map<std::string, std::shared_ptr<DeviceRegion>> device_regions_;
   std::map<std::string, std::shared_ptr<GraphRunner>> runners_;  // graph models being served
+  std::mutex gate_mu_;
+  std::condition_variable gate_cv_;
+  int capturing_ = 0, launching_ = 0;
 
   // device BYTES path
   DevicePipe pipe_;

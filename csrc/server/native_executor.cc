@@ -1333,6 +1333,7 @@ class NativeExecutor::GraphRunner {
       inst.free_events.pop_back();
     }
     lk->unlock();
+    owner_->EnterLaunch();
     const uint64_t t_exec = NowNs();
     const GraphPipe::Graph* graph = nullptr;
     for (const auto& g : inst.graphs)
@@ -1368,6 +1369,7 @@ class NativeExecutor::GraphRunner {
       }
       if (rc == 0) rc = pipe_.event_record(event, inst.stream);
     }
+    owner_->LeaveLaunch();
     const uint64_t t_enq = NowNs();
     if (rc != 0) {
       // nothing (or not everything) was enqueued: whatever was runs to its end before the regions go back,
@@ -1497,6 +1499,34 @@ void NativeExecutor::DisableGraphModel(const std::string& model) {
     }
   }
   for (auto& r : going) r->Stop();  // requests that found the runner a moment ago are answered or handed back
+}
+
+void NativeExecutor::BeginCapture() {
+  std::unique_lock<std::mutex> lk(gate_mu_);
+  ++capturing_;
+  gate_cv_.wait(lk, [this] { return launching_ == 0; });
+}
+
+void NativeExecutor::EndCapture() {
+  {
+    std::lock_guard<std::mutex> lk(gate_mu_);
+    if (capturing_ > 0) --capturing_;
+  }
+  gate_cv_.notify_all();
+}
+
+void NativeExecutor::EnterLaunch() {
+  std::unique_lock<std::mutex> lk(gate_mu_);
+  gate_cv_.wait(lk, [this] { return capturing_ == 0; });
+  ++launching_;
+}
+
+void NativeExecutor::LeaveLaunch() {
+  {
+    std::lock_guard<std::mutex> lk(gate_mu_);
+    --launching_;
+  }
+  gate_cv_.notify_all();
 }
 
 void NativeExecutor::QuiesceGraphModels() {

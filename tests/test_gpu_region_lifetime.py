@@ -26,6 +26,16 @@ def served():
     srv.stop()
 
 
+@pytest.fixture(scope="module")
+def served_general():
+    """The same server with the native graph path off: every request takes the general (Python) path."""
+    from triton_client_amd.server import spawn_server
+
+    srv = spawn_server(models=["resnet50"], gpu=0, env={"TCA_RESNET_GRAPH_CACHE": "48", "TCA_NATIVE_GRAPHS": "0"})
+    yield srv
+    srv.stop()
+
+
 def _make_regions(hipshm, client, tag, n, x):
     regions = []
     for i in range(n):
@@ -157,12 +167,16 @@ def _plan_counters(served):
     return {line.split()[0]: int(line.split()[1]) for line in text.splitlines() if line.startswith("tca_request_plan_")}
 
 
-def test_repeated_messages_run_from_their_plan_on_fresh_contents(served):
-    """The same raw request message again and again is queued from its stored plan: every repeat still
-    reads what is in the region NOW and writes its own answer, and a region that comes back under the
-    same name with other memory behind it gets a new plan."""
+@pytest.mark.parametrize("path", ["native", "general"])
+def test_repeated_messages_run_from_their_plan_on_fresh_contents(request, path):
+    """The same raw request message again and again: every repeat still reads what is in the region NOW and
+    writes its own answer, and a region that comes back under the same name with other memory behind it is
+    addressed through the new mapping.  On the general path the repeats are queued from the stored plan of
+    the message (counted); the native graph path parses every message and looks the regions up again."""
     import tritonclient.grpc as g
     import tritonclient.utils.cuda_shared_memory as hipshm
+
+    served = request.getfixturevalue("served" if path == "native" else "served_general")
 
     rng = np.random.default_rng(7)
     x1 = rng.standard_normal((B, 3, 224, 224)).astype(np.float16)
@@ -188,8 +202,11 @@ def test_repeated_messages_run_from_their_plan_on_fresh_contents(served):
             c.infer("resnet50", ins, outputs=outs)
             np.testing.assert_allclose(read(hout), ref, rtol=1e-2, atol=1e-2)
         mid = _plan_counters(served)
-        assert mid["tca_request_plan_stored_total"] == before["tca_request_plan_stored_total"] + 1
-        assert mid["tca_request_plan_hits_total"] == before["tca_request_plan_hits_total"] + 3
+        if path == "general":
+            assert mid["tca_request_plan_stored_total"] == before["tca_request_plan_stored_total"] + 1
+            assert mid["tca_request_plan_hits_total"] == before["tca_request_plan_hits_total"] + 3
+        else:
+            assert mid == before  # none of the four reached the interpreter
         # the same names, other memory: the old plan must not be used (its views alias the old mapping)
         c.unregister_cuda_shared_memory("plan_in0")
         c.unregister_cuda_shared_memory("plan_out0")
@@ -204,16 +221,18 @@ def test_repeated_messages_run_from_their_plan_on_fresh_contents(served):
             np.testing.assert_allclose(read(hout2), ref2, rtol=1e-2, atol=1e-2)
         assert np.all(read(hout) == -7.0)  # nothing wrote through the old mapping
         after = _plan_counters(served)
-        assert after["tca_request_plan_stored_total"] == mid["tca_request_plan_stored_total"] + 1
-        assert after["tca_request_plan_hits_total"] == mid["tca_request_plan_hits_total"] + 1
+        if path == "general":
+            assert after["tca_request_plan_stored_total"] == mid["tca_request_plan_stored_total"] + 1
+            assert after["tca_request_plan_hits_total"] == mid["tca_request_plan_hits_total"] + 1
         c.unregister_cuda_shared_memory("plan_in0")
         c.unregister_cuda_shared_memory("plan_out0")
         for h in (hin, hout, hin2, hout2):
             hipshm.destroy_shared_memory_region(h)
 
 
-def test_repeated_rest_bodies_run_from_their_plan(served):
+def test_repeated_rest_bodies_run_from_their_plan(served_general):
     """The REST front keeps plans too (small JSON bodies whose tensors are region references)."""
+    served = served_general
     import tritonclient.http as h
     import tritonclient.utils.cuda_shared_memory as hipshm
 

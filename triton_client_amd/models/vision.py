@@ -202,7 +202,8 @@ class ResNet50(Model):
     fill_window_us = 600
     # batch sizes whose HIP graphs are captured at load time (the batcher merges
     # concurrent requests, so totals other than the request batch show up)
-    warmup_batches = (8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128)
+    warmup_batches = (1, 2, 4, 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128)
+    pad_batches = True  # other totals run on the next of these sizes: nothing is captured while serving
     # Served by the native executor from captured graphs (requests with both tensors in device shared
     # memory never reach the interpreter): the batch sizes it holds a graph for.  A merged batch runs on
     # the smallest graph that holds it, so every request batch size - 1 included, perf_analyzer's
@@ -216,11 +217,14 @@ class ResNet50(Model):
         super().__init__()
         if os.environ.get("TCA_RESNET_MAX_BATCH"):  # experiments with the batcher's largest merged batch
             self.max_batch_size = int(os.environ["TCA_RESNET_MAX_BATCH"])
-            self.warmup_batches = tuple(range(8, self.max_batch_size + 1, 8))
+            self.warmup_batches = (1, 2, 4) + tuple(range(8, self.max_batch_size + 1, 8))
         self._torch = None
         self._net = None
         self._graphs = _GraphCache(int(os.environ.get("TCA_RESNET_GRAPH_CACHE", "512")))
         self._io_buffers = {}  # (instance, batch) -> static (input, output) pair for callers without stable buffers
+        # entered around every stream capture: the server installs the native executor's gate here, which keeps
+        # that executor's own graph launches (other threads, same streams) out of the way of a capture
+        self.capture_gate = None
         self.online_captures = 0  # graphs captured after the server finished loading the model (``warmed_up``)
         self.warmed_up = False
         self._lock = threading.RLock()
@@ -585,10 +589,13 @@ class ResNet50(Model):
 
     def native_graph_plan(self, instances):
         """What the native executor needs to serve this model by itself: for every execution instance and
-        every size in ``native_batches`` a captured graph over static buffers of its own (the dynamic batcher
-        of the general path keeps its own, so both may enqueue on the instances' streams at any time), as
-        ``(instance, batch, hipGraphExec_t, input address, output address)``, plus the stream handles and the
-        bytes per batch entry.  ``keep`` holds the graphs and buffers alive."""
+        every size in ``native_batches`` a captured graph over static buffers of its own, as
+        ``(instance, batch, hipGraphExec_t, input address, output address)``, plus stream handles and the
+        bytes per batch entry.  These graphs run on streams of their own and allocate their activations
+        from pools of their own (one per instance): the dynamic batcher of the general path may replay ITS
+        graphs on the model's streams at any moment from another thread, and two graph launches into one
+        stream from two threads are not ordered as units - their kernels would interleave on shared
+        activation memory.  ``keep`` holds graphs, buffers, streams and pools alive."""
         torch = self._torch
         graphs, keep = [], []
         sizes = [b for b in self.native_batches if b <= self.max_batch_size]
@@ -596,27 +603,33 @@ class ResNet50(Model):
             sizes.append(self.max_batch_size)
         spec = self.inputs[0]
         in_dtype = torch.float16 if spec.datatype == "FP16" else torch.float32
+        streams = [torch.cuda.Stream(device=self._device) for _ in range(instances)]
+        pools = [torch.cuda.graph_pool_handle() for _ in range(instances)]
         for inst in range(instances):
+            stream = streams[inst]
             for b in sizes:
                 x = torch.zeros((b, *spec.dims), device=self._device, dtype=in_dtype)
                 out = torch.empty((b, *self.outputs[0].dims), device=self._device, dtype=torch.float32)
-                self.execute({spec.name: x, "__out__" + self.outputs[0].name: out, "__instance__": inst}, None)
-                self._streams[inst].synchronize()
-                entry = self._native_graph_entry(x, out, inst)
-                graphs.append((inst, b, int(entry[0].raw_cuda_graph_exec()), int(entry[1].data_ptr()),
-                               int(out.data_ptr())))
-                keep.append((entry, x, out))
-        return {"graphs": graphs, "keep": keep, "streams": [int(s.cuda_stream) for s in self._streams[:instances]],
-                "in_row_bytes": int(keep[0][0][1][0].numel() * keep[0][0][1].element_size()),
+                with torch.no_grad():
+                    with torch.cuda.stream(stream):
+                        self._forward_into(x, out)  # warm-up for this shape on this stream
+                    stream.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    gate = self.capture_gate
+                    if gate is not None:
+                        gate.begin_capture()
+                    try:
+                        with torch.cuda.graph(g, pool=pools[inst], stream=stream):
+                            self._forward_into(x, out)
+                    finally:
+                        if gate is not None:
+                            gate.end_capture()
+                graphs.append((inst, b, int(g.raw_cuda_graph_exec()), int(x.data_ptr()), int(out.data_ptr())))
+                keep.append((g, x, out))
+        keep.append((streams, pools))
+        return {"graphs": graphs, "keep": keep, "streams": [int(s.cuda_stream) for s in streams],
+                "in_row_bytes": int(keep[0][1][0].numel() * keep[0][1].element_size()),
                 "out_row_bytes": int(keep[0][2][0].numel() * 4), "max_batch": int(self.max_batch_size)}
-
-    def _native_graph_entry(self, x, out, instance):
-        """The captured graph that reads ``x`` and writes ``out`` (captured by the ``execute`` just before)."""
-        with self._lock:
-            entry = self._graphs.get((x.shape[0], x.data_ptr(), out.data_ptr(), instance))
-        if entry is None:
-            raise ModelError("no captured graph for the native executor's buffers")
-        return entry
 
     def _capture(self, x, out, stream, instance=0):
         """Capture one forward as a HIP graph.  All graphs of one execution instance allocate
@@ -636,8 +649,15 @@ class ResNet50(Model):
                     self._graph_pools[instance] = torch.cuda.graph_pool_handle()
                 pool = self._graph_pools[instance]
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=stream):
-                self._forward_into(x, out)
+            gate = self.capture_gate
+            if gate is not None:
+                gate.begin_capture()
+            try:
+                with torch.cuda.graph(g, pool=pool, stream=stream):
+                    self._forward_into(x, out)
+            finally:
+                if gate is not None:
+                    gate.end_capture()
         return (g, x, out)  # keep the tensors (hence the IPC mappings) alive
 
     @property

@@ -120,6 +120,12 @@ class DynamicBatcher:
         self._busy_lock = threading.Lock()
         self._pins = {}  # input address of a single zero-copy request -> instance that captured its graph first
         self._launch_hist = {} if os.environ.get("TCA_BATCHER_STATS") else None
+        # Models that ask for it (``pad_batches``) run a batch on the static buffers of the next size their
+        # graphs were captured for at load time (rows past the batch are computed and ignored): no request,
+        # whatever its batch size, makes the server capture a graph while it is serving.
+        sizes = sorted(b for b in getattr(self.model, "warmup_batches", ()) if b <= self.max_batch)
+        self._pad_sizes = sizes if (sizes and getattr(self.model, "pad_batches", False)
+                                    and getattr(self.model, "use_graphs", False)) else None
         # per instance: [ring of [pinned uint8 buffer, event of its last H2D copy, bytes used], next entry]
         self._stagers = [None] * self.instances  # per instance: native wire stager (pinned ring + copy stream)
         self.q = queue.Queue()
@@ -380,6 +386,22 @@ class DynamicBatcher:
             self._static[key] = bufs
         return bufs
 
+    def _padded(self, total):
+        if self._pad_sizes is not None:
+            for size in self._pad_sizes:
+                if size >= total:
+                    return size
+        return total
+
+    def _zero_copy_single(self, it, in_name):
+        """A lone request whose tensors are in registered device regions replays a graph captured for exactly
+        those addresses (no copy at all) - while the native executor does not serve the model: it takes such
+        requests itself, and graphs captured per client region are captures made while serving."""
+        if getattr(self.lm, "native_graphs", None) is not None:
+            return False
+        return in_name in it.stable and all(
+            (it.dests[ro.name] if it.dests is not None else None) is not None or ro.shm is not None for ro in it.requested)
+
     def _launch(self, group, total):
         hint = None
         if self.instances > 1 and len(group) == 1:
@@ -408,7 +430,7 @@ class DynamicBatcher:
         t_exec = time.perf_counter_ns()
         stream = self._stream_of(inst)
         pending = []  # (item, dev_inputs or None, host copies)
-        if len(group) == 1:
+        if len(group) == 1 and (self._pad_sizes is None or self._zero_copy_single(group[0], in_name)):
             it = group[0]
             host_x = it.inputs[in_name]
             staged = isinstance(host_x, np.ndarray) and host_x.dtype != np.object_
@@ -453,7 +475,7 @@ class DynamicBatcher:
             else:
                 in_dtype = first.dtype
             tail = tuple(first.shape[1:])
-            sbuf, obuf = self._static_buffers(inst, total, in_name, in_dtype, tail, out_name)
+            sbuf, obuf = self._static_buffers(inst, self._padded(total), in_name, in_dtype, tail, out_name)
             from ..ops.copy import batched_copy
 
             # gather: device-resident inputs (hipshm) go through ONE batched copy
@@ -504,9 +526,9 @@ class DynamicBatcher:
                     result = self._host_copies(it, {out_name: piece}, stream, own_static=True)
                 else:
                     if host_all is None:
-                        host_all = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+                        host_all = torch.empty((total, *out.shape[1:]), dtype=out.dtype, pin_memory=True)
                         with torch.cuda.stream(stream):
-                            host_all.copy_(out, non_blocking=True)
+                            host_all.copy_(out[:total], non_blocking=True)  # not the padding rows
                     result = {out_name: host_all[row - it.batch: row]}
                 pending.append((it, dev_inputs, result))
             batched_copy(scatter, stream)

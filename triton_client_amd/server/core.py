@@ -678,6 +678,8 @@ class InferenceCore:
         with self._lock:
             loaded = list(self._loaded.values())
         for lm in loaded:
+            if hasattr(lm.model, "capture_gate"):
+                lm.model.capture_gate = executor  # stream captures and the executor's graph launches take turns
             self._sync_native(lm)
 
     def _attach_device_bytes(self, executor):
@@ -832,6 +834,8 @@ class InferenceCore:
         except ModelError as e:
             raise ServerError(f"failed to load '{name}': {e}", 400) from None
         lm = LoadedModel(model, self.gpu)
+        if hasattr(model, "capture_gate") and self.native is not None:
+            model.capture_gate = self.native
         if hasattr(model, "evict_region"):
             self.devshm.on_close.append(model.evict_region)
         if model.device == "gpu" and model.dynamic_batching:
