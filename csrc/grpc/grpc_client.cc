@@ -889,8 +889,10 @@ Error InferenceServerGrpcClient::AsyncInfer(OnCompleteFn callback, const InferOp
     *call_id = call;
     if (!*finished) async->calls.insert(call);
   }
-  channel_->SendMessage(call, std::move(request), true, compressed);
+  // the hand-over to the channel's thread ends the caller's send phase; stamped before it because the answer
+  // (and the statistics update that reads the stamps) can arrive before SendMessage returns
   timers->CaptureTimestamp(RequestTimers::Kind::SEND_END);
+  channel_->SendMessage(call, std::move(request), true, compressed);
   return Error::Success();
 }
 

@@ -1270,8 +1270,9 @@ class NativeExecutor::GraphRunner {
         }
         if (!have_slot) {
           // GPU full: wait for a slot, absorbing arrivals meanwhile
-          WaitFor(cv_, lk, us(500), [this] { return stop_ || !queue_.empty() || inflight_ < cap_; });
-          if (stop_ && queue_.empty() && inflight_ >= cap_) continue;  // keeps waiting for the slot
+          // (not woken by stop_: a predicate that stays true would spin here with the lock held while the
+          // completers need it to free the slot)
+          WaitFor(cv_, lk, us(500), [this] { return !queue_.empty() || inflight_ < cap_; });
           continue;
         }
         const uint64_t now_ns = NowNs();

@@ -741,7 +741,9 @@ void GraphPath() {
     std::atomic<int> verdicts{0};
     std::memset(base, 0, 64);
     for (int i = 0; i < 20; ++i) {
-      std::string request = GraphRequest("dev", 1, 0, 256, 64);
+      // every request has an output range of its own: two instances may scatter at the same time
+      const int64_t slot = static_cast<int64_t>(i % kThreads) * kSlot;
+      std::string request = GraphRequest("dev", 1, slot, slot + 256 + 8 * (i / kThreads), 8);
       if (ex.TryGrpcAsync(&request, &response, [&](bool, std::string&&) { ++verdicts; }) != NativeExecutor::Outcome::kDeferred)
         ++verdicts;
     }

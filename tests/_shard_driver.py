@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="GPU ordinal shared by every rank (omit: host memory)")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--flags", default=None)
+    ap.add_argument("--first-seq", type=int, default=0, help="start counting steps here (just below 2^32: the wrap)")
+    ap.add_argument("--kill-worker-after", type=int, default=None,
+                    help="kill worker 1 after this many steps; the next steps must raise ShardError")
     args = ap.parse_args()
     import torch
 
@@ -52,7 +55,8 @@ def main():
                 out.copy_(x.float().reshape(x.shape[0], -1).sum(dim=1, keepdim=True).expand_as(out))
 
     root = ShardRoot(forward, args.world, args.device or 0, 6 * 2, out_cols * 4, max_rows, streams=streams,
-                     mode=args.mode, flags=args.flags, timeout_ms=20000)
+                     mode=args.mode, flags=args.flags, timeout_ms=4000 if args.kill_worker_after is not None else 20000,
+                     first_seq=args.first_seq)
     root.spawn_workers([args.device or 0] * (args.world - 1), model="test_rowsum", sample_shape=sample_shape,
                        out_shape=(out_cols,), startup_timeout=300.0)
     # steady state: no control traffic between the processes, no process-group call (direct mode)
@@ -73,6 +77,8 @@ def main():
             setattr(dist, name, counted)
     rows_seen = []
     pending = []
+    if args.kill_worker_after is not None:
+        return killed_worker(args, root, dev, sample_shape, out_cols)
     for step in range(args.steps):
         rows = [max_rows, 8, 5, 1, 2, 17][step % 6]
         slot = step % SLOTS
@@ -105,6 +111,40 @@ def main():
     assert dist_calls[0] == 0, f"{dist_calls[0]} process-group calls in steady state"
     print("SHARD_OK", json.dumps({"steps": args.steps, "rows": rows_seen, "mode": args.mode,
                                   "control_messages": conn_calls[0], "process_group_calls": dist_calls[0]}))
+
+
+def killed_worker(args, root, dev, sample_shape, out_cols):
+    """A worker process dies in the middle of serving: within the group's time limit a step (or the
+    check behind it) raises ShardError naming the worker; nothing hangs, close() still returns."""
+    import time
+
+    import torch
+
+    from triton_client_amd.parallel.sharded import ShardError
+
+    def one(step):
+        x = (torch.arange(8 * 6, dtype=torch.float32).reshape(8, *sample_shape) % 13 + step).half().to(dev)
+        out = torch.zeros(8, out_cols, dtype=torch.float32, device=dev)
+        root.step(x, out, step % 2)
+        root.check()
+        return out
+
+    for step in range(args.kill_worker_after):
+        one(step)
+    root._procs[0].kill()
+    t0 = time.monotonic()
+    error = None
+    try:
+        for step in range(64):  # far more than the ring holds
+            one(args.kill_worker_after + step)
+            time.sleep(0.05)
+    except ShardError as e:
+        error = str(e)
+    waited = time.monotonic() - t0
+    t1 = time.monotonic()
+    root.close()
+    print("SHARD_OK", json.dumps({"error": error, "seconds_to_error": round(waited, 2),
+                                  "seconds_to_close": round(time.monotonic() - t1, 2)}))
 
 
 if __name__ == "__main__":

@@ -30,6 +30,66 @@ def test_sharded_group_host_backed(world, mode):
     assert info["control_messages"] == 0 and info["process_group_calls"] == 0
 
 
+@pytest.mark.parametrize("mode", ["direct", "rccl"])
+def test_sequence_numbers_cross_the_32_bit_wrap(mode):
+    """Mailbox words, flags and the progress word hold 32 bits of an unbounded step count."""
+    info = _run(["--world", "3", "--mode", mode, "--steps", "24", "--first-seq", str(2 ** 32 - 9)],
+                {"TCA_HIPSHM_FAKE": "1"})
+    assert info["steps"] == 24
+
+
+def test_next_seq_skips_the_empty_word():
+    from triton_client_amd.parallel.sharded import RING, _behind, next_seq
+
+    assert next_seq(0) == 1 and next_seq(2 ** 32 - 2) == 2 ** 32 - 1 and next_seq(2 ** 32 - 1) == 2 ** 32 + 1
+    assert _behind(2 ** 32 + 3, 0xFFFFFFFE) == 5 and _behind(7, 7) == 0 and _behind(7, 9) == 0
+    assert _behind(2 ** 32 + 1 + RING, 1) == RING
+
+
+def test_worker_death_is_reported_not_waited_out():
+    info = _run(["--world", "3", "--mode", "direct", "--kill-worker-after", "5"], {"TCA_HIPSHM_FAKE": "1"}, timeout=120)
+    assert info["error"] and "worker 1" in info["error"], info
+    assert info["seconds_to_error"] < 6 and info["seconds_to_close"] < 30, info
+
+
+def test_worker_that_never_starts_fails_the_setup_at_once():
+    """A replica process that exits during start-up ends accept_workers() with its exit code."""
+    import time
+
+    code = (
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['TCA_HIPSHM_FAKE'] = '1'\n"
+        "from triton_client_amd.parallel.sharded import ShardRoot, ShardError\n"
+        "root = ShardRoot(lambda x, o, s: None, 2, 0, 12, 16, 32)\n"
+        "t0 = time.monotonic()\n"
+        "try:\n"
+        "    root.spawn_workers([0], model='no_such_model', startup_timeout=120.0)\n"
+        "    print('NO_ERROR')\n"
+        "except ShardError as e:\n"
+        "    print('SHARD_ERROR', round(time.monotonic() - t0, 1), e)\n"
+        "root.close()\n" % ROOT)
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110,
+                       env=dict(os.environ, TCA_HIPSHM_FAKE="1"))
+    assert "SHARD_ERROR" in p.stdout, p.stdout + p.stderr[-2000:]
+    assert "exited with code" in p.stdout or "failed during setup" in p.stdout, p.stdout
+    assert time.monotonic() - t0 < 60
+
+
+def test_server_outlives_a_dead_replica():
+    """Requests for the sharded model fail with the worker's name within the group's time limit; other
+    models, health and shutdown are unaffected."""
+    p = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tests", "_shard_server_driver.py")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, TCA_HIPSHM_FAKE="1"))
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("SHARD_SERVER_OK ")]
+    assert p.returncode == 0 and lines, f"rc={p.returncode}\n{p.stdout[-3000:]}\n{p.stderr[-3000:]}"
+    report = json.loads(lines[-1][len("SHARD_SERVER_OK "):])
+    assert all(e and "shard worker 2" in e for e in report["errors"]), report
+    assert report["seconds_for_three_failed_requests"] < 10 and report["seconds_to_stop"] < 30, report
+    assert report["live"] and report["ready"] and report["other_model_ready"], report
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", ["kernel", "stream"])
 def test_sharded_group_hip_ipc_one_gpu(flags):

@@ -57,6 +57,26 @@ class ShardError(RuntimeError):
     pass
 
 
+_MASK = 0xFFFFFFFF
+
+
+def next_seq(seq):
+    """Sequence number of the step after ``seq``.  Mailbox words, flags and the completed word are
+    32 bits wide and hold ``seq & 0xFFFFFFFF``; word value 0 means "never written", so numbers whose
+    low word is 0 are skipped (root and workers skip the same ones and stay on the same ring index)."""
+    seq += 1
+    if seq & _MASK == 0:
+        seq += 1
+    return seq
+
+
+def _behind(seq, done_word):
+    """How many steps the 32-bit progress word ``done_word`` lags ``seq`` (wrap-safe; a word that is
+    ahead counts as 0)."""
+    lag = (seq - done_word) & _MASK
+    return 0 if lag >= 0x80000000 else lag
+
+
 class ControlBlock:
     """Host shared memory of one sharded group: per worker ``RING`` mailbox lines
     ``[seq, slot, rows, out_row]`` and one line with the sequence number of the last step
@@ -145,9 +165,10 @@ class _HostLane:
                 ctypes.memmove(dst, src, n)
 
     def set_flag(self, ptr, value):
-        ctypes.c_uint32.from_address(ptr).value = value
+        ctypes.c_uint32.from_address(ptr).value = value & _MASK
 
     def wait_flag(self, ptr, value, error_ptr):
+        value &= _MASK
         cell = ctypes.c_uint32.from_address(ptr)
         deadline = time.monotonic() + self.timeout_s
         while ((cell.value - value) & 0xFFFFFFFF) >= 0x80000000:
@@ -179,13 +200,15 @@ class _GpuLane:
     def set_flag(self, ptr, value):
         from ..ops._device import check, lib
 
-        check(lib().tca_flag_set(self.stream.cuda_stream, ptr, value, self.flag_mode), "flag set")
+        check(lib().tca_flag_set(self.stream.cuda_stream, ptr, value & _MASK, self.flag_mode), "flag set")
 
     def wait_flag(self, ptr, value, error_ptr):
         from ..ops._device import check, lib
 
-        check(lib().tca_flag_wait(self.stream.cuda_stream, ptr, value, self.flag_mode, self.timeout_ms, error_ptr),
-              "flag wait")
+        # kernel flags compare with wrap-around (signed difference); the command processor's packet is a
+        # plain >=, which ShardRoot.step guards by refusing to run a "stream" group up to the wrap
+        check(lib().tca_flag_wait(self.stream.cuda_stream, ptr, value & _MASK, self.flag_mode, self.timeout_ms,
+                                  error_ptr), "flag wait")
 
     def wait_for(self, other):
         self.stream.wait_stream(other.stream)
@@ -232,10 +255,11 @@ class ShardRoot:
     max_rows : largest batch a step may carry
     streams : per slot, the compute stream (``torch.cuda.Stream``) ``forward`` uses; None on CPU
     mode : "direct" | "rccl"
+    first_seq : sequence number the group counts on from (tests start just below 2^32 to cross the wrap)
     """
 
     def __init__(self, forward, world, device, sample_bytes, out_row_bytes, max_rows, streams=None, mode="direct",
-                 flags=None, timeout_ms=5000, tag=None):
+                 flags=None, timeout_ms=5000, tag=None, first_seq=0):
         from ..utils import hip_shared_memory as hipshm
 
         if mode not in ("direct", "rccl"):
@@ -250,7 +274,8 @@ class ShardRoot:
         self.tag = tag or f"tca_shard_{os.getpid()}_{id(self) & 0xFFFF:x}"
         self._hipshm = hipshm
         self._lock = threading.Lock()
-        self._seq = 0
+        self._seq = int(first_seq)
+        self._first_seq = int(first_seq)
         self._conns = []
         self._procs = []
         self._peer_inbox = []
@@ -263,6 +288,14 @@ class ShardRoot:
         self.flag_mode = _flag_mode(flags, self.device, self.fake)
         self.control = ControlBlock(f"/{self.tag}_ctl", max(1, self.workers), create=True)
         self.flags = FlagBlock(hipshm, max(1, self.workers), self.device, f"{self.tag}_flags")
+        if self._first_seq:
+            # flags as the step before would have left them (a zero flag is "ahead" of numbers near the wrap)
+            words = np.zeros(self.flags.nbytes // 4, dtype=np.uint32)
+            for w in range(max(1, self.workers)):
+                for slot in range(SLOTS):
+                    for kind in (FlagBlock.READY, FlagBlock.DONE):
+                        words[self.flags.offset(kind, w, slot) // 4] = self._first_seq & _MASK
+            hipshm.set_shared_memory_region(self.flags.region, [words])
         self._last_check = time.monotonic()
         if self.fake:
             self.compute = [_HostLane(self.timeout_ms) for _ in range(SLOTS)]
@@ -309,11 +342,21 @@ class ShardRoot:
         """Handshake with every worker: collect inbox handles, hand out the control block, the
         gather buffer and (mode "rccl") the rendezvous of the process group."""
         hipshm = self._hipshm
-        self._listener._listener._socket.settimeout(timeout)
+        deadline = time.monotonic() + timeout
+        # short accept timeouts: a worker that died (bad device ordinal, import error, out of memory) is
+        # reported with its exit code at once instead of after the whole start-up allowance
+        self._listener._listener._socket.settimeout(0.5)
         hello = {}
-        for _ in range(self.workers):
-            conn = self._listener.accept()
-            info = conn.recv()
+        while len(hello) < self.workers:
+            try:
+                conn = self._listener.accept()
+            except OSError:  # socket.timeout
+                self._check_procs()
+                if time.monotonic() > deadline:
+                    raise ShardError(f"only {len(hello)} of {self.workers} shard workers connected within "
+                                     f"{timeout:.0f} s") from None
+                continue
+            info = self._recv(conn, deadline, "hello")
             hello[info["rank"]] = (conn, info)
         if sorted(hello) != list(range(1, self.world)):
             raise ShardError(f"unexpected worker ranks {sorted(hello)}")
@@ -336,7 +379,7 @@ class ShardRoot:
                        "gather": self.gather._raw, "gather_bytes": self.gather.byte_size, "gather_device": self.device,
                        "shard_rows": self.shard_rows, "sample_bytes": self.sample_bytes,
                        "out_row_bytes": self.out_row_bytes, "mode": self.mode, "flag_mode": self.flag_mode,
-                       "timeout_ms": self.timeout_ms, "dist_port": dist_port})
+                       "timeout_ms": self.timeout_ms, "dist_port": dist_port, "first_seq": self._first_seq})
         if self.mode == "rccl":
             import torch
             import torch.distributed as dist
@@ -348,11 +391,28 @@ class ShardRoot:
                                         world_size=self.world, **kwargs)
             self.group = dist
         for conn in self._conns:
-            ack = conn.recv()
+            ack = self._recv(conn, deadline, "ready")
             if ack != "ready":
                 raise ShardError(f"worker failed during setup: {ack}")
         self._listener.close()
         self._listener = None
+
+    def _check_procs(self):
+        for rank, p in enumerate(self._procs, start=1):
+            if p.poll() is not None:
+                raise ShardError(f"shard worker {rank} exited with code {p.returncode}")
+
+    def _recv(self, conn, deadline, what):
+        """One setup message from a worker; gives up when a worker process has exited or at the deadline."""
+        while not conn.poll(0.5):
+            self._check_procs()
+            if time.monotonic() > deadline:
+                raise ShardError(f"no '{what}' message from a shard worker before the start-up deadline")
+        try:
+            return conn.recv()
+        except (EOFError, OSError) as e:
+            self._check_procs()
+            raise ShardError(f"a shard worker closed its setup connection before '{what}'") from e
 
     # ------------------------------------------------------------------- step
     def _post(self, w, seq, slot, rows, out_row):
@@ -360,25 +420,24 @@ class ShardRoot:
         ctl = self.control
         # never run more than a ring ahead of the slowest worker (the batcher's in-flight cap
         # keeps it far below that; this is the backstop)
-        if seq > RING:
+        if seq > self._first_seq + RING:
             deadline = time.monotonic() + self.timeout_ms / 1e3
             done_word = ctl.completed_word(w)
-            while int(ctl.words[done_word]) + RING <= seq:
+            while _behind(seq, int(ctl.words[done_word])) >= RING:
                 if time.monotonic() > deadline:
                     raise ShardError(f"worker {w + 1} is more than {RING} steps behind")
+                self._check_procs()
                 time.sleep(0.0002)
         base = ctl.mail_word(w, seq % RING)
         ctl.words[base + 1] = slot
         ctl.words[base + 2] = rows
         ctl.words[base + 3] = out_row
-        ctl.words[base] = seq
+        ctl.words[base] = seq & _MASK
 
     def check(self, force=True):
         """Raise if a wait on either side gave up (a process died or hangs).  The flags live in
         device memory: steps look at them a few times per second (``force=False``)."""
-        for rank, p in enumerate(self._procs, start=1):
-            if p.poll() is not None:
-                raise ShardError(f"shard worker {rank} exited with code {p.returncode}")
+        self._check_procs()
         now = time.monotonic()
         if not force and now - self._last_check < 0.25:
             return
@@ -403,8 +462,9 @@ class ShardRoot:
         compute, copy = self.compute[slot], self.copy[slot]
         flags = self.flags
         with self._lock:  # sequence numbers are handed out in submission order
-            self._seq += 1
-            seq = self._seq
+            if self.flag_mode == 1 and self._seq >= _MASK - RING:
+                raise ShardError("a group with command-processor flags must be rebuilt before 2^32 steps")
+            seq = self._seq = next_seq(self._seq)
             start = n0
             plan = []
             for w in range(self.workers):
@@ -471,7 +531,7 @@ class ShardRoot:
     def close(self):
         try:
             with self._lock:
-                self._seq += 1
+                self._seq = next_seq(self._seq)
                 for w in range(self.workers):
                     self._post(w, self._seq, 0, STOP_ROWS, 0)
         except Exception:
@@ -595,12 +655,12 @@ class ShardWorker:
         """Process mailbox entries in sequence order until the stop entry arrives."""
         ctl = self.control
         w = self.rank - 1
-        seq = 1
+        seq = next_seq(int(self.cfg.get("first_seq", 0)))
         idle_since = time.monotonic()
         while True:
             base = ctl.mail_word(w, seq % RING)
             self._publish_completed(w)
-            while int(ctl.words[base]) != seq:
+            while int(ctl.words[base]) != seq & _MASK:
                 # spin briefly (a loaded group posts every few hundred microseconds), then back off
                 if time.monotonic() - idle_since > 0.005:
                     time.sleep(0.0002)
@@ -615,7 +675,7 @@ class ShardWorker:
                 return
             self._step(w, seq, slot, rows, out_row)
             self._track(seq, slot)
-            seq += 1
+            seq = next_seq(seq)
             idle_since = time.monotonic()
 
     def _step(self, w, seq, slot, rows, out_row):
@@ -652,7 +712,7 @@ class ShardWorker:
         while self._inflight and (self._inflight[0][1] is None or self._inflight[0][1].query()):
             done = self._inflight.pop(0)[0]
         if done is not None:
-            self.control.words[self.control.completed_word(w)] = done
+            self.control.words[self.control.completed_word(w)] = done & _MASK
 
     def _step_rccl(self, slot, rows):
         if not rows:
