@@ -71,7 +71,7 @@ def parse_args():
                     help="seconds the load generator may take for one phase before the run is abandoned")
     ap.add_argument("--mode", choices=["serve", "fanout", "image_client"], default="serve",
                     help="fanout: also measure resnet50_sharded (one request's batch split over the GPUs), "
-                         "reported under extra.fanout; runs by itself when there are several ranks")
+                         "reported under extra.fanout; opt-in, with several ranks too")
     ap.add_argument("--fanout-devices", default=None,
                     help="GPU ordinals of the fan-out replicas besides GPU 0 (default: every other rank's GPU; "
                          "'0,0' rehearses three replicas on one GPU)")
@@ -131,18 +131,20 @@ def read_line(proc, timeout, what):
     return proc.stdout.readline()
 
 
-def check_contents(args, device, slots, hipshm):
+def check_contents(args, device, slots, hipshm, batch=None, model_name=None):
     """Reads the input and output regions of a few slots back and compares the served logits with a forward of
     the same inputs by a model instance loaded in THIS process (same seeded random-init weights).  The server
-    merges requests into batches of other sizes, which run other tile variants, so the comparison is to fp16
-    rounding, not bit for bit; the images differ (structured_images), so do the logits, and that is asserted."""
+    merges requests into batches of other sizes (or splits them over replicas), which run other tile variants,
+    so the comparison is to fp16 rounding, not bit for bit; the images differ (structured_images), so do the
+    logits, and that is asserted."""
     import numpy as np
     import torch
 
     from triton_client_amd.models import MODEL_ZOO
 
-    b = args.batch
-    model = MODEL_ZOO[args.model]()
+    b = batch or args.batch
+    chunk = min(b, 64)
+    model = MODEL_ZOO[model_name or args.model]()
     model.load(device)
     try:
         served, direct = [], []
@@ -150,23 +152,26 @@ def check_contents(args, device, slots, hipshm):
             x = hipshm.get_contents_as_numpy(hin, np.float16, [b, 3, 224, 224])
             served.append(np.array(hipshm.get_contents_as_numpy(hout, np.float32, [b, 1000]), copy=True))
             xt = torch.from_numpy(np.array(x, copy=True)).to(f"cuda:{device}")
-            out = model.run(xt)
-            model.stream.synchronize()
-            direct.append(out.float().cpu().numpy())
+            for s in range(0, b, chunk):
+                out = model.run(xt[s: s + chunk])
+                model.stream.synchronize()
+                direct.append(out.float().cpu().numpy())
         served, direct = np.concatenate(served), np.concatenate(direct)
     finally:
         model.unload()
     err = float(np.abs(served - direct).max())
     scale = float(np.abs(direct).max())
-    # how far apart the logits of two different images are at least (every pair of the checked images)
+    # how far apart the logits of two different images are at least (every pair of up to 64 checked images,
+    # taken evenly from all of them)
     n = served.shape[0]
-    apart = min(float(np.abs(served[i] - served[j]).max()) for i in range(n) for j in range(i + 1, n))
+    some = served[np.linspace(0, n - 1, min(n, 64)).astype(int)]
+    apart = min(float(np.abs(some[i] - some[j]).max()) for i in range(len(some)) for j in range(i + 1, len(some)))
     ok = bool(np.isfinite(served).all() and err <= 0.05 * scale and apart > 4.0 * err
               and (served.argmax(1) == direct.argmax(1)).mean() >= 0.9)
     return {"max_abs_err": round(err, 5), "logit_scale": round(scale, 4), "images_checked": int(n),
             "min_distance_between_images": round(apart, 4),
             "top1_agreement": round(float((served.argmax(1) == direct.argmax(1)).mean()), 4),
-            "reference": "model.run of the same input regions in the benchmark process (batch 8)", "ok": ok}
+            "reference": f"model.run of the same input regions in the benchmark process (batch {chunk})", "ok": ok}
 
 
 def measure_native(args, url, device, dist, label, mode=None, steps=None, per_step=None, warmup_requests=None,
@@ -206,13 +211,18 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
     control = grpcclient.InferenceServerClient(url if args.protocol == "grpc" else args.control_url)
     regions = []
     cleanup = []
-    tiled = None
-    if b > 64:
-        # large batches (fan-out runs): the kernel's output for 8 images, repeated
-        x8 = torch.empty(8, 3, 224, 224, device=f"cuda:{device}", dtype=torch.float16)
-        pre(images[:8], x8)
-        tiled = x8.repeat(-(-b // 8), 1, 1, 1)[:b].contiguous()
-        torch.cuda.synchronize()
+    big = {}
+
+    def big_batch(key):
+        # large batches (fan-out runs): the preprocessing kernel in chunks of 64 images, eight different sets
+        if key not in big:
+            x = torch.empty(b, 3, 224, 224, device=f"cuda:{device}", dtype=torch.float16)
+            imgs = structured_images(b, first=1000 * device + key * b)
+            for s in range(0, b, 64):
+                pre(imgs[s: s + 64], x[s: s + 64])
+            torch.cuda.synchronize()
+            big[key] = x
+        return big[key]
 
     def barrier():
         if dist is not None:
@@ -231,8 +241,8 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
                 hin = hipshm.create_shared_memory_region(f"in_{device}_{i}", in_bytes, device)
                 hout = hipshm.create_shared_memory_region(f"out_{device}_{i}", out_bytes, device)
                 regions += [hin, hout]
-                if tiled is not None:
-                    hipshm.set_shared_memory_region_from_dlpack(hin, [tiled])
+                if b > 64:
+                    hipshm.set_shared_memory_region_from_dlpack(hin, [big_batch(i % 8)])
                 else:
                     # every slot its own images; the HIP kernel writes the batch straight into the region
                     # (the sweep's extra slots repeat the image sets of the first 64)
@@ -284,12 +294,12 @@ def measure_native(args, url, device, dist, label, mode=None, steps=None, per_st
         if result["errors"] or result["requests"] != steps * per_step:
             raise RuntimeError(f"load generator reported {result['errors']} errors "
                                f"({result['requests']} of {steps * per_step} requests): {result['first_error']}")
-        if check and mode == "hip" and tiled is None:
+        if check and mode == "hip":
             try:
                 # slots far apart: their requests were merged into different batches
                 picks = sorted({0, concurrency // 3, (2 * concurrency) // 3, concurrency - 1})
                 extra["check"] = check_contents(args, device, [(regions[2 * i], regions[2 * i + 1]) for i in picks],
-                                                hipshm)
+                                                hipshm, batch=b, model_name=check if isinstance(check, str) else None)
             except Exception as e:  # noqa: BLE001 - reported in the line; the throughput result stands
                 extra["check"] = {"error": f"{type(e).__name__}: {e}"[:400], "ok": False}
         if levels and mode == "hip":
@@ -624,7 +634,10 @@ def measure_fanout(args, world):
     same_gpu = len(set(devices + [0])) < replicas
     batch = 32 * replicas
     out = {"replicas": replicas, "devices": [0] + devices, "batch_per_request": batch, "concurrency": 8,
-           "note": "replicas share one GPU (rehearsal)" if same_gpu else "one replica per GPU"}
+           "note": "replicas share one GPU (rehearsal)" if same_gpu else "one replica per GPU",
+           "parity": "the served logits are compared with a single-GPU forward of the same regions in this run "
+                     "(check); no earlier measurement on more than one GPU exists to compare the rates with "
+                     "(parity unpinned on >1 GPU)"}
     for mode in [m for m in args.fanout_modes.split(",") if m]:
         if mode == "rccl" and same_gpu:
             out[mode] = {"skipped": "RCCL needs one GPU per rank"}
@@ -640,10 +653,11 @@ def measure_fanout(args, world):
             url = server.grpc_url if args.protocol == "grpc" else server.http_url
             r = measure_native(args, url, 0, None, f"fanout-{mode}", mode="hip", steps=1,
                                per_step=args.fanout_requests, warmup_requests=64, model="resnet50_sharded",
-                               batch=batch, concurrency=8)
+                               batch=batch, concurrency=8, check="resnet50")
             out[mode] = {"infer_per_sec": round(r["infer_per_sec"], 1), "p50_latency_us": round(r["p50_us"], 1),
                          "p99_latency_us": round(r["p99_us"], 1), "requests": r["requests"],
-                         "elapsed_s": round(r["elapsed_s"], 4), "startup_s": round(start_s, 1)}
+                         "elapsed_s": round(r["elapsed_s"], 4), "startup_s": round(start_s, 1),
+                         "check": r.get("check")}
         except BaseException as e:  # noqa: BLE001 - the headline number must survive
             out[mode] = {"error": f"{type(e).__name__}: {e}"[:500]}
         finally:
@@ -692,6 +706,47 @@ def fanout_in_child(args, world):
         for key, value in result.items():
             merged.setdefault(key, value)
     return merged
+
+
+def preflight(args, dist, rank, world, device):
+    """Before anything is measured with several ranks: an all-reduce whose result only comes out right when
+    every rank takes part, the identity of the GPU each rank holds (one GPU per rank on the RCCL backend, or
+    the run stops here), the time of a small all-reduce and - rank 0 - the peer-access matrix of the visible
+    GPUs (hipDeviceCanAccessPeer)."""
+    import torch
+
+    dev = args.reduce_device
+    t = torch.full((8,), float(rank + 1), device=dev, dtype=torch.float64)
+    dist.all_reduce(t)
+    reduced_ok = bool((t == world * (world + 1) / 2).all().item())
+    prop = torch.cuda.get_device_properties(device)
+    ident = f"{int(prop.pci_domain_id):04x}:{int(prop.pci_bus_id):02x}:{int(prop.pci_device_id):02x}"
+    held = [None] * world
+    dist.all_gather_object(held, {"rank": rank, "gpu": ident, "ordinal": device, "name": prop.name})
+    ranks_seen = sorted(h["rank"] for h in held)
+    distinct = len({h["gpu"] for h in held})
+    small = torch.ones(1024, device=dev)
+    for _ in range(3):
+        dist.all_reduce(small)
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        dist.all_reduce(small)
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    all_reduce_us = (time.perf_counter() - t0) / 20 * 1e6
+    rccl = args.dist_backend == "nccl"
+    ok = reduced_ok and ranks_seen == list(range(world)) and (distinct == world or not rccl)
+    n = torch.cuda.device_count()
+    report = {"rccl_ranks_verified": bool(ok and rccl), "ranks_verified": bool(ok), "backend": "rccl" if rccl else "gloo",
+              "ranks": world, "distinct_gpus": distinct, "gpus": [h["gpu"] for h in held],
+              "all_reduce_4KB_us": round(all_reduce_us, 1),
+              "peer_access": [[1 if a == b else int(torch.cuda.can_device_access_peer(a, b)) for b in range(n)]
+                              for a in range(n)] if rank == 0 else None}
+    if not ok:
+        raise SystemExit(f"rank {rank}: preflight failed before measuring: {json.dumps(report)}")
+    return report
 
 
 def launch_ranks(args):
@@ -788,6 +843,7 @@ def main():
             dist_mod.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_mod
     args.reduce_device = f"cuda:{device}" if args.dist_backend == "nccl" else "cpu"
+    checked = preflight(args, dist, rank, world, device) if dist is not None else None
 
     from triton_client_amd.server import spawn_server
 
@@ -829,7 +885,10 @@ def main():
         dist.barrier()
     if not args.no_extras and args.client == "native" and args.mode == "serve":
         extras["secondary"] = measure_secondary(args, device, dist)  # every rank takes part (collectives inside)
-    if not args.no_extras and args.client == "native" and (args.mode == "fanout" or world > 1):
+    if not args.no_extras and args.client == "native" and args.mode != "fanout" and world > 1:
+        extras["fanout"] = {"skipped": "opt-in (--mode fanout): the cross-GPU data plane of resnet50_sharded has "
+                                       "only run with its replicas sharing one GPU; parity unpinned on >1 GPU"}
+    if not args.no_extras and args.client == "native" and args.mode == "fanout":
         # every rank's server is down; rank 0 serves resnet50_sharded with one replica per GPU
         # the other ranks wait on the host (a collective barrier would spin on their GPUs,
         # which are the replicas' GPUs now)
@@ -884,6 +943,8 @@ def main():
                 "parallelism": f"dp{n} (one model instance per GPU, requests sharded)",
             },
         }
+        if checked is not None:
+            line["preflight"] = checked
         if extras:
             line["extra"] = extras
         print(json.dumps(line), flush=True)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="GPU ordinal shared by every rank (omit: host memory)")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--flags", default=None)
+    ap.add_argument("--gather", default=None, help="mode rccl: p2p | collective")
     ap.add_argument("--first-seq", type=int, default=0, help="start counting steps here (just below 2^32: the wrap)")
     ap.add_argument("--kill-worker-after", type=int, default=None,
                     help="kill worker 1 after this many steps; the next steps must raise ShardError")
@@ -56,7 +57,7 @@ def main():
 
     root = ShardRoot(forward, args.world, args.device or 0, 6 * 2, out_cols * 4, max_rows, streams=streams,
                      mode=args.mode, flags=args.flags, timeout_ms=4000 if args.kill_worker_after is not None else 20000,
-                     first_seq=args.first_seq)
+                     first_seq=args.first_seq, gather=args.gather)
     root.spawn_workers([args.device or 0] * (args.world - 1), model="test_rowsum", sample_shape=sample_shape,
                        out_shape=(out_cols,), startup_timeout=300.0)
     # steady state: no control traffic between the processes, no process-group call (direct mode)

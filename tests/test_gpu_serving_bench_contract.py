@@ -76,6 +76,19 @@ def test_two_ranks_print_one_aggregate_line():
     _check(_json_line(done.stdout), 2, 3, 1)
 
 
+def test_fanout_is_opt_in_and_checks_its_answers():
+    """``--mode fanout`` on a one-GPU box: three replicas share the GPU (rehearsal of the cross-GPU form);
+    the logits the group served are compared with a single-GPU forward in the same run."""
+    cmd = [sys.executable, "bench.py", "--mode", "fanout", "--steps", "2", "--warmup", "1", "--requests-per-step", "64",
+           "--concurrency", "16", "--extra-requests", "128", "--fanout-requests", "48", "--fanout-modes", "direct"]
+    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert done.returncode == 0, done.stderr[-2000:]
+    fan = _json_line(done.stdout)["extra"]["fanout"]
+    assert fan["replicas"] == 3 and "parity unpinned on >1 GPU" in fan["parity"]
+    assert "error" not in fan["direct"], fan
+    assert fan["direct"]["infer_per_sec"] > 0 and fan["direct"]["check"]["ok"] is True, fan
+
+
 def test_gpus_flag_alone_starts_the_ranks():
     """``python bench.py --gpus 2`` with no launcher: bench.py starts both ranks itself."""
     env = dict(os.environ, TCA_BENCH_DIST_BACKEND="gloo")
@@ -89,6 +102,29 @@ def test_gpus_flag_alone_starts_the_ranks():
     line = _json_line(done.stdout)
     _check(line, 2, 3, 1)
     assert line["rank_backend"] == "gloo"
+    # the ranks proved themselves before measuring (on one GPU: gloo, so not "RCCL verified"); fan-out is opt-in
+    pre = line["preflight"]
+    assert pre["ranks_verified"] is True and pre["rccl_ranks_verified"] is False and pre["ranks"] == 2
+    assert pre["peer_access"] == [[1]] and "parity unpinned on >1 GPU" in line["extra"]["fanout"]["skipped"]
+
+
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs")
+def test_two_ranks_on_two_gpus_over_rccl():
+    """One rank per GPU on the RCCL backend, with the fan-out measured across the two GPUs."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TCA_BENCH_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--mode", "fanout", "--steps", "3", "--warmup", "1",
+           "--requests-per-step", "64", "--concurrency", "16", "--extra-requests", "128", "--fanout-requests", "64"]
+    done = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=400, env=env)
+    assert done.returncode == 0, done.stderr[-2000:]
+    line = _json_line(done.stdout)
+    assert line["n_gpus"] == 2 and line["rank_backend"] == "rccl"
+    assert line["preflight"]["rccl_ranks_verified"] is True and line["preflight"]["distinct_gpus"] == 2
+    fan = line["extra"]["fanout"]
+    for mode in ("direct", "rccl"):
+        assert "error" not in fan[mode], fan
+        assert fan[mode]["check"]["ok"] is True, fan
 
 
 def test_rank_count_must_match_gpus_flag():

@@ -30,6 +30,15 @@ def test_sharded_group_host_backed(world, mode):
     assert info["control_messages"] == 0 and info["process_group_calls"] == 0
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_collective_gather_brings_every_shard_home(world):
+    """Mode "rccl" with one all_gather_into_tensor per step for the output rows (gloo here): steps of 32, 8,
+    5, 1, 2 and 17 rows cover even and uneven shards and steps smaller than the group."""
+    info = _run(["--world", str(world), "--mode", "rccl", "--gather", "collective", "--steps", "12"],
+                {"TCA_HIPSHM_FAKE": "1"})
+    assert info["steps"] == 12
+
+
 @pytest.mark.parametrize("mode", ["direct", "rccl"])
 def test_sequence_numbers_cross_the_32_bit_wrap(mode):
     """Mailbox words, flags and the progress word hold 32 bits of an unbounded step count."""
@@ -96,3 +105,31 @@ def test_sharded_group_hip_ipc_one_gpu(flags):
     """Real hipIpc mappings, peer stores and flags polled by the GPU: three ranks share GPU 0."""
     info = _run(["--world", "3", "--mode", "direct", "--device", "0", "--steps", "12", "--flags", flags], {})
     assert info["control_messages"] == 0 and info["process_group_calls"] == 0
+
+
+@pytest.mark.gpu
+def test_fanout_bench_rehearsal_on_one_gpu():
+    """``tools/fanout_bench.py`` with three replica processes on GPU 0: peer-access matrix, step times and
+    bytes per second into every peer's inbox."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fanout_bench.py"), "--devices", "0,0", "--batch", "96",
+                        "--iters", "40", "--modes", "direct"], cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines[0]["peer_access"] == {"gpus": [0], "matrix": [[1]]}
+    run = lines[1]
+    assert run["mode"] == "direct" and run["replicas"] == 3 and run["same_gpu"] is True
+    assert len(run["peer_GBps"]) == 2 and all(v > 1 for v in run["peer_GBps"]) and run["all_peers_GBps"] > 1
+    assert run["us_per_step_pipelined"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs")
+@pytest.mark.parametrize("mode,gather", [("direct", None), ("rccl", "p2p"), ("rccl", "collective")])
+def test_sharded_group_across_two_gpus(mode, gather):
+    """The cross-GPU data plane proper: rank 1 on GPU 1 (xGMI peer stores / RCCL)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fanout_bench.py"), "--devices", "1", "--batch", "64",
+                        "--iters", "40", "--modes", mode] + (["--gather", gather] if gather else []), cwd=ROOT,
+                       capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines[1]["mode"] == mode and lines[1]["same_gpu"] is False and lines[1]["us_per_step_pipelined"] > 0

@@ -7,7 +7,10 @@ replica processes and fp32 logit rows come back, with replicas that compute noth
 
 Prints one JSON line per transport ("direct": peer stores + device flags, "rccl": point-to-
 point operations of torch.distributed) with the time per step, the bytes per second that
-leave the ingest GPU and that figure per xGMI link (one link per peer)."""
+leave the ingest GPU and that figure per xGMI link (one link per peer); for "direct" also the bytes
+per second of the copy kernel into each peer's inbox by itself ("peer_GBps", one entry per replica
+process) and into all of them in one launch, and before the runs the peer-access matrix of the GPUs
+involved (hipDeviceCanAccessPeer)."""
 import argparse
 import json
 import os
@@ -25,6 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--modes", default="direct,rccl")
+    ap.add_argument("--gather", default=None, choices=[None, "p2p", "collective"], help="mode rccl: how output rows return")
     ap.add_argument("--flags", default=None, choices=[None, "kernel", "stream"])
     args = ap.parse_args()
     import torch
@@ -44,13 +48,16 @@ def main():
     sample_bytes, out_row_bytes = 3 * 224 * 224 * 2, 1000 * 4
     x = torch.randn(args.batch, 3, 224, 224, device=dev).half()
     out = torch.zeros(args.batch, 1000, device=dev)
+    gpus = sorted(set([0] + devices))
+    print(json.dumps({"peer_access": {"gpus": gpus, "matrix": [[1 if a == b else int(torch.cuda.can_device_access_peer(a, b))
+                                                                for b in gpus] for a in gpus]}}), flush=True)
     for mode in [m for m in args.modes.split(",") if m]:
         if mode == "rccl" and same_gpu:
             print(json.dumps({"mode": mode, "skipped": "RCCL needs one GPU per rank"}))
             continue
         streams = [torch.cuda.Stream(device=dev) for _ in range(SLOTS)]
         root = ShardRoot(lambda a, b, slot: None, world, 0, sample_bytes, out_row_bytes, args.batch, streams=streams,
-                         mode=mode, flags=args.flags, timeout_ms=20000)
+                         mode=mode, flags=args.flags, timeout_ms=20000, gather=args.gather)
         try:
             root.spawn_workers(devices, model="test_noop", startup_timeout=300.0)
 
@@ -71,6 +78,10 @@ def main():
                 run(1)
                 lat.append(time.perf_counter() - t1)
             root.check()
+            peers = None
+            if mode == "direct":
+                shard = -(-args.batch // world) * sample_bytes
+                peers = root.peer_bandwidth(x.data_ptr(), shard, iters=50)
         finally:
             root.close()
         sent = (args.batch - -(-args.batch // world)) * sample_bytes  # bytes that leave the ingest GPU per step
@@ -78,7 +89,10 @@ def main():
                           "batch": args.batch, "us_per_step_pipelined": round(dt * 1e6, 1),
                           "us_per_step_isolated_p50": round(sorted(lat)[len(lat) // 2] * 1e6, 1),
                           "GBps_out_of_root": round(sent / dt / 1e9, 1),
-                          "GBps_per_link": round(sent / dt / 1e9 / len(devices), 1)}), flush=True)
+                          "GBps_per_link": round(sent / dt / 1e9 / len(devices), 1),
+                          **({"peer_bytes": peers["bytes"],
+                              "peer_GBps": [round(v / 1e9, 1) for v in peers["per_peer"]],
+                              "all_peers_GBps": round(peers["all_peers"] / 1e9, 1)} if peers else {})}), flush=True)
 
 
 if __name__ == "__main__":

@@ -107,6 +107,13 @@ class BatchFanout:
         dist.all_gather_into_tensor(out, padded, group=self.group)
         return torch.cat([out[r * widest: r * widest + n] for r, n in enumerate(sizes)], dim=0)
 
+    def gather_padded(self, padded, out):
+        """The serving form of :meth:`gather`: no allocation, one equal-size collective.  ``padded`` holds
+        this rank's rows padded to the widest shard, ``out`` (``world x widest`` rows, caller owned) receives
+        every rank's block; the caller knows the shard sizes and drops the padding rows."""
+        self.dist.all_gather_into_tensor(out, padded, group=self.group)
+        return out
+
     def gather_to_root(self, local, batch):
         """Only the root receives the concatenation; other ranks get ``None``."""
         import torch

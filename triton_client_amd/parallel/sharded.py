@@ -24,7 +24,10 @@ Steady state needs no host round trip between the processes and no process-group
   that stores into the peers' inboxes (hipIpc mappings), i.e. over all xGMI links at once;
   output rows come back as one small device-to-device copy per worker into the root's gather
   buffer.  ``mode="rccl"``: grouped point-to-point sends / receives of ``torch.distributed``
-  (backend "nccl" is RCCL), received straight into the caller's output rows.
+  (backend "nccl" is RCCL), received straight into the caller's output rows; with
+  ``gather="collective"`` the output rows come back in ONE ``all_gather_into_tensor`` of blocks
+  padded to the widest shard (:meth:`parallel.fanout.BatchFanout.gather_padded`) instead of one
+  receive per worker - the rows are small, so the step is bound by the number of operations.
 
 Two slots (one per execution instance of the root's model) double-buffer the inboxes and the
 gather buffer, so the scatter of one step overlaps the forward of the previous one.
@@ -255,11 +258,13 @@ class ShardRoot:
     max_rows : largest batch a step may carry
     streams : per slot, the compute stream (``torch.cuda.Stream``) ``forward`` uses; None on CPU
     mode : "direct" | "rccl"
+    gather : mode "rccl" only: "p2p" (default; one receive per worker) | "collective" (one all-gather);
+        ``TCA_SHARD_GATHER`` when None
     first_seq : sequence number the group counts on from (tests start just below 2^32 to cross the wrap)
     """
 
     def __init__(self, forward, world, device, sample_bytes, out_row_bytes, max_rows, streams=None, mode="direct",
-                 flags=None, timeout_ms=5000, tag=None, first_seq=0):
+                 flags=None, timeout_ms=5000, tag=None, first_seq=0, gather=None):
         from ..utils import hip_shared_memory as hipshm
 
         if mode not in ("direct", "rccl"):
@@ -270,6 +275,13 @@ class ShardRoot:
         self.device = int(device)
         self.sample_bytes, self.out_row_bytes, self.max_rows = int(sample_bytes), int(out_row_bytes), int(max_rows)
         self.mode = mode
+        self.gather_mode = gather or os.environ.get("TCA_SHARD_GATHER") or "p2p"
+        if self.gather_mode not in ("p2p", "collective"):
+            raise ValueError("gather must be 'p2p' or 'collective'")
+        if mode != "rccl":
+            self.gather_mode = "p2p"
+        self._fan = None
+        self._gather_bufs = {}
         self.timeout_ms = int(timeout_ms)
         self.tag = tag or f"tca_shard_{os.getpid()}_{id(self) & 0xFFFF:x}"
         self._hipshm = hipshm
@@ -379,7 +391,8 @@ class ShardRoot:
                        "gather": self.gather._raw, "gather_bytes": self.gather.byte_size, "gather_device": self.device,
                        "shard_rows": self.shard_rows, "sample_bytes": self.sample_bytes,
                        "out_row_bytes": self.out_row_bytes, "mode": self.mode, "flag_mode": self.flag_mode,
-                       "timeout_ms": self.timeout_ms, "dist_port": dist_port, "first_seq": self._first_seq})
+                       "timeout_ms": self.timeout_ms, "dist_port": dist_port, "first_seq": self._first_seq,
+                       "gather_mode": self.gather_mode})
         if self.mode == "rccl":
             import torch
             import torch.distributed as dist
@@ -415,7 +428,7 @@ class ShardRoot:
             raise ShardError(f"a shard worker closed its setup connection before '{what}'") from e
 
     # ------------------------------------------------------------------- step
-    def _post(self, w, seq, slot, rows, out_row):
+    def _post(self, w, seq, slot, rows, out_row, total=0):
         """Mailbox entry for worker ``w`` (0-based): payload first, sequence number last."""
         ctl = self.control
         # never run more than a ring ahead of the slowest worker (the batcher's in-flight cap
@@ -432,6 +445,7 @@ class ShardRoot:
         ctl.words[base + 1] = slot
         ctl.words[base + 2] = rows
         ctl.words[base + 3] = out_row
+        ctl.words[base + 4] = total  # rows of the whole step: the widest shard sizes the collective gather
         ctl.words[base] = seq & _MASK
 
     def check(self, force=True):
@@ -469,7 +483,7 @@ class ShardRoot:
             plan = []
             for w in range(self.workers):
                 n = sizes[w + 1]
-                self._post(w, seq, slot, n, start - n0)
+                self._post(w, seq, slot, n, start - n0, rows)
                 plan.append((w, start, n))
                 start += n
             if self.mode == "direct":
@@ -479,6 +493,9 @@ class ShardRoot:
                               n * self.sample_bytes) for w, s, n in plan])
                 for w, _, _ in plan:
                     copy.set_flag(flags.ptr(FlagBlock.READY, w, slot), seq)
+            elif self.gather_mode == "collective":
+                self._rccl_collective(x, out, plan, compute, slot, sizes)
+                return out
             else:
                 sends = self._rccl_group(x, out, plan, compute, send=True)
                 if n0:
@@ -496,6 +513,26 @@ class ShardRoot:
                 compute.copies([(self.gather.address + gather_off, out_ptr + n0 * self.out_row_bytes,
                                  (rows - n0) * self.out_row_bytes)])
         return out
+
+    def peer_bandwidth(self, src_ptr, nbytes, iters=20):
+        """Mode "direct": bytes per second of the copy kernel storing ``nbytes`` from ``src_ptr`` into each
+        worker's inbox, one peer at a time and then all peers in one launch (what a step does).  Returns
+        ``{"per_peer": [...], "all_peers": total bytes per second}``."""
+        lane = self.copy[0]
+        nbytes = min(int(nbytes), *(m.byte_size for m in self._peer_inbox))
+
+        def timed(triples):
+            lane.copies(triples)
+            lane.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                lane.copies(triples)
+            lane.synchronize()
+            return sum(t[2] for t in triples) * iters / max(time.perf_counter() - t0, 1e-9)
+
+        each = [timed([(src_ptr, m.address, nbytes)]) for m in self._peer_inbox]
+        together = timed([(src_ptr, m.address, nbytes) for m in self._peer_inbox])
+        return {"bytes": nbytes, "per_peer": each, "all_peers": together}
 
     def _rccl_group(self, x, out, plan, compute, send):
         """One group of point-to-point operations: every shard leaves in one group (all links
@@ -515,6 +552,38 @@ class ShardRoot:
             return dist.batch_isend_irecv(ops)
         with torch.cuda.stream(compute.stream):
             return dist.batch_isend_irecv(ops)
+
+    def _rccl_collective(self, x, out, plan, compute, slot, sizes):
+        """Shards leave in one group of sends; the root's rows are computed into a block padded to the
+        widest shard; one all-gather brings every rank's block; one batched copy drops the padding."""
+        import contextlib
+
+        import torch
+
+        from .fanout import BatchFanout
+
+        if self._fan is None:
+            self._fan = BatchFanout(group=None, root=0)
+        widest, n0 = sizes[0], sizes[0]
+        key = (slot, out.dtype, tuple(out.shape[1:]))
+        bufs = self._gather_bufs.get(key)
+        if bufs is None:
+            pad = torch.zeros((self.shard_rows, *out.shape[1:]), dtype=out.dtype, device=out.device)
+            full = torch.zeros((self.world * self.shard_rows, *out.shape[1:]), dtype=out.dtype, device=out.device)
+            bufs = self._gather_bufs[key] = (pad, full)
+        pad, full = bufs
+        sends = self._rccl_group(x, out, plan, compute, send=True)
+        self.forward(x[:n0], pad[:n0], slot)
+        self._rccl_wait(sends, compute)
+        with contextlib.nullcontext() if self.fake else torch.cuda.stream(compute.stream):
+            self._fan.gather_padded(pad[:widest], full[: self.world * widest])
+        row = self.out_row_bytes
+        triples, start = [], 0
+        for r, n in enumerate(sizes):
+            if n:
+                triples.append((full.data_ptr() + r * widest * row, out.data_ptr() + start * row, n * row))
+            start += n
+        compute.copies(triples)
 
     def _rccl_wait(self, works, compute):
         if self.fake:
@@ -673,6 +742,7 @@ class ShardWorker:
             slot, rows, out_row = int(ctl.words[base + 1]), int(ctl.words[base + 2]), int(ctl.words[base + 3])
             if rows == STOP_ROWS:
                 return
+            self._total = int(ctl.words[base + 4])
             self._step(w, seq, slot, rows, out_row)
             self._track(seq, slot)
             seq = next_seq(seq)
@@ -715,6 +785,8 @@ class ShardWorker:
             self.control.words[self.control.completed_word(w)] = done & _MASK
 
     def _step_rccl(self, slot, rows):
+        if self.cfg.get("gather_mode") == "collective":
+            return self._step_rccl_collective(slot, rows)
         if not rows:
             return
         x, out = self._tensors(slot, rows)
@@ -735,6 +807,37 @@ class ShardWorker:
             self.forward(x, out, slot)
             for work in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, 0)]):
                 work.wait()
+
+    def _step_rccl_collective(self, slot, rows):
+        """Every rank joins the all-gather of every step, rows or not (a step smaller than the group)."""
+        import contextlib
+
+        import torch
+
+        from ..utils import triton_to_np_dtype
+        from .fanout import BatchFanout
+
+        dist = self.group
+        world = self.cfg["world"]
+        widest = -(-self._total // world)
+        bufs = self._views.get(("gather", slot))
+        if bufs is None:
+            dt = torch.from_numpy(np.zeros(1, dtype=triton_to_np_dtype(self.out_dtype))).dtype
+            device = "cpu" if self.fake else f"cuda:{self.device}"
+            pad = torch.zeros((self.shard_rows, *self.out_shape), dtype=dt, device=device)
+            full = torch.zeros((world * self.shard_rows, *self.out_shape), dtype=dt, device=device)
+            bufs = self._views[("gather", slot)] = (pad, full, BatchFanout(group=None, root=0))
+        pad, full, fan = bufs
+        with contextlib.nullcontext() if self.fake else torch.cuda.stream(self.streams[slot]):
+            if rows:
+                x, _ = self._tensors(slot, rows)
+                if self.fake:
+                    dist.recv(x, src=0)
+                else:
+                    for work in dist.batch_isend_irecv([dist.P2POp(dist.irecv, x, 0)]):
+                        work.wait()
+                self.forward(x, pad[:rows], slot)
+            fan.gather_padded(pad[:widest], full[: world * widest])
 
     def close(self):
         for lane in getattr(self, "lanes", ()):
