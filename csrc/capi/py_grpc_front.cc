@@ -23,8 +23,10 @@
 #include <Python.h>
 
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -45,6 +47,14 @@ struct PyGrpcFront {
   PyObject* on_cancel;
   tca::capi::GilFunnel* funnel;  // null with one reactor: that thread calls Python itself
   std::shared_ptr<tca::server::NativeExecutor>* native;  // null: every request goes to Python
+  // Streams one of whose messages went to Python: from then on all their messages do.  A message answered
+  // here is on the wire at once, one handed to Python answers later - answering a later message natively
+  // would let its response overtake the earlier one's on the same stream.
+  struct PythonStreams {
+    std::mutex mu;
+    std::unordered_set<uint64_t> calls;
+  };
+  PythonStreams* python_streams;
 };
 
 // Owns one received message and exposes it through the buffer protocol, so numpy
@@ -241,6 +251,7 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
       return -1;
     }
   }
+  self->python_streams = new PyGrpcFront::PythonStreams();
   Py_INCREF(on_unary);
   Py_INCREF(on_msg);
   Py_INCREF(on_end);
@@ -275,10 +286,19 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
   };
   h.on_stream_message = [self](uint64_t call, const std::string& method, std::string&& request) {
     if (self->native != nullptr && method == "ModelStreamInfer") {
+      bool python_owned;
+      {
+        std::lock_guard<std::mutex> lk(self->python_streams->mu);
+        python_owned = self->python_streams->calls.count(call) != 0;
+      }
       std::vector<std::string> responses;
-      if ((*self->native)->TryGrpcStream(request, &responses)) {  // answered here, in order, no interpreter
+      if (!python_owned && (*self->native)->TryGrpcStream(request, &responses)) {  // answered here, in order
         for (auto& m : responses) self->front->Send(call, std::move(m));
         return;
+      }
+      if (!python_owned) {
+        std::lock_guard<std::mutex> lk(self->python_streams->mu);
+        self->python_streams->calls.insert(call);
       }
     }
     auto req = std::make_shared<std::string>(std::move(request));
@@ -288,9 +308,17 @@ int FrontInit(PyObject* self_obj, PyObject* args, PyObject* kwargs) {
     });
   };
   h.on_stream_end = [self](uint64_t call) {
+    {
+      std::lock_guard<std::mutex> lk(self->python_streams->mu);
+      self->python_streams->calls.erase(call);
+    }
     WithGil(self, [self, call] { CallPython(self->on_stream_end, "(K)", static_cast<unsigned long long>(call)); });
   };
   h.on_cancel = [self](uint64_t call) {
+    {
+      std::lock_guard<std::mutex> lk(self->python_streams->mu);
+      self->python_streams->calls.erase(call);
+    }
     WithGil(self, [self, call] { CallPython(self->on_cancel, "(K)", static_cast<unsigned long long>(call)); });
   };
   self->front = new tca::server::GrpcServerFront(host, port, threads, {"ModelStreamInfer"}, std::move(h));
@@ -320,6 +348,8 @@ void FrontDealloc(PyObject* self_obj) {
   self->funnel = nullptr;
   delete self->native;
   self->native = nullptr;
+  delete self->python_streams;
+  self->python_streams = nullptr;
   Py_XDECREF(self->on_unary);
   Py_XDECREF(self->on_stream_message);
   Py_XDECREF(self->on_stream_end);

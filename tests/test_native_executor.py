@@ -312,6 +312,34 @@ def test_ordinary_models_over_streams(servers):
         assert c.get_inference_statistics("simple").model_stats[0].inference_count - s0 == 12
 
 
+def test_a_sequence_stream_with_python_messages_keeps_its_order(servers):
+    """One stream carrying a sequence whose messages alternate between ones the executor answers and ones only
+    Python answers (a request parameter): a message answered natively is on the wire at once, one handed to
+    Python runs later, so once a stream's message went to Python its later messages follow it there - the
+    accumulator sees the values in request order and the responses come back in that order."""
+    on, off = servers
+
+    def send(c):
+        for k in range(10):
+            extra = {"parameters": {"note": "x"}} if k in (1, 4, 5) else {}
+            c.async_stream_infer("simple_sequence", _sequence_request(grpcclient, 1 + k), sequence_id=4242,
+                                 sequence_start=(k == 0), sequence_end=(k == 9), request_id=str(k), **extra)
+
+    rows = []
+    before = _handled(on)
+    for srv in (on, off):
+        pairs = _stream_collect(srv.grpc_url, send, 10)
+        assert all(e is None for _, e in pairs)
+        rows.append([(int(r.get_response().id), int(r.as_numpy("OUTPUT")[0, 0])) for r, _ in pairs])
+    assert [i for i, _ in rows[0]] == list(range(10)) and rows[0] == rows[1]
+    assert _handled(on) == before + 1  # the message ahead of the first Python one
+    # a new stream starts on the native path again
+    pairs = _stream_collect(on.grpc_url, lambda c: c.async_stream_infer(
+        "simple_sequence", _sequence_request(grpcclient, 3), sequence_id=4243, sequence_start=True, sequence_end=True), 1)
+    assert pairs[0][1] is None and _handled(on) == before + 2
+    assert on._native.open_sequences("simple_sequence") == 0
+
+
 def _sequence_request(mod, value):
     return [mod.InferInput("INPUT", [1, 1], "INT32").set_data_from_numpy(np.array([[value]], dtype=np.int32))]
 

@@ -172,6 +172,51 @@ def test_busy_region_survives_an_unregister_that_times_out():
         core.shutdown()
 
 
+def test_busy_region_stays_mirrored_in_the_native_executor():
+    """Unregister first takes the region away from the native executor, then waits for the leases of the
+    general path; when those outlast the limit the region stays registered - in the executor too."""
+    from triton_client_amd.server.core import InferenceCore, ServerError
+
+    class Mirror:
+        def __init__(self):
+            self.regions, self.calls = {}, []
+
+        def register_region(self, name, key, offset, size):
+            self.regions[name] = (key, offset, size)
+            self.calls.append(("register", name))
+
+        def unregister_region(self, name):
+            self.calls.append(("unregister", name))
+            if name:
+                self.regions.pop(name, None)
+            else:
+                self.regions.clear()
+
+    core = InferenceCore(models=["simple"])
+    region = _region("/tca_busy_mirror", 64)
+    try:
+        mirror = core.sysshm.native = Mirror()
+        core.sysshm.drain_timeout_s = 0.05
+        core.sysshm.register("m", region.key, 0, 64)
+        assert mirror.regions == {"m": ("/tca_busy_mirror", 0, 64)}
+        lease = core.sysshm.acquire("m")
+        with pytest.raises(ServerError):
+            core.sysshm.unregister("m")
+        assert mirror.regions == {"m": ("/tca_busy_mirror", 0, 64)}, mirror.calls
+        with pytest.raises(ServerError):
+            core.sysshm.unregister("")  # "all regions" keeps the busy one on both sides as well
+        assert list(mirror.regions) == ["m"]
+        core.sysshm.release(lease)
+        core.sysshm.unregister("m")
+        assert mirror.regions == {} and core.sysshm.status() == []
+    finally:
+        import tritonclient.utils.shared_memory as shm
+
+        core.sysshm.native = None
+        shm.destroy_shared_memory_region(region)
+        core.shutdown()
+
+
 def test_request_plans_follow_region_and_model_identity():
     """A stored plan (``InferenceCore.try_planned``) queues a repeat of the same raw message without a parse,
     holds the region leases for it, and is dropped as soon as a region of that name is another registration

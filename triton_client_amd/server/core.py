@@ -333,10 +333,18 @@ class SystemShmRegistry(_Leased):
             self.native.unregister_region(name or "")  # first: no request may start on a region that is going away
         with self._lock:
             removed, busy = self._drain(name)
+            still = [(n, self._regions[n]) for n in busy if n in self._regions]
         for _, entry in removed:
             try:
                 sysshm.destroy_shared_memory_region(entry.handle)
             except sysshm.SharedMemoryException:
+                pass
+        for n, entry in still:
+            # still leased by requests of the general path: it stays registered, so the executor serves it again
+            try:
+                self.native.register_region(n, entry.key if entry.key.startswith("/") else "/" + entry.key,
+                                            entry.offset, entry.byte_size)
+            except (ValueError, AttributeError):
                 pass
         self._raise_busy(busy)
 
@@ -454,6 +462,9 @@ class DeviceShmRegistry(_Leased):
             for n, _ in removed:
                 for key in [k for k in self._views if k[0] == n]:
                     del self._views[key]
+            still = [(n, self._regions[n]) for n in busy if n in self._regions]
+        for n, entry in still:
+            self._mirror(n, entry)  # still leased by the general path: stays registered, natively too
         for n, entry in removed:
             base, size = entry.mapping.address, entry.byte_size
             for hook in list(self.on_close):
