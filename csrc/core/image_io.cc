@@ -204,8 +204,9 @@ Error ReadImageFile(const std::string& path, DecodedImage* out) {
   if (!f) return Error("unable to open '" + path + "'");
   std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   if (bytes.size() >= 2 && bytes[0] == 0x89 && bytes[1] == 'P') return DecodePng(bytes.data(), bytes.size(), out);
+  if (bytes.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) return DecodeJpeg(bytes.data(), bytes.size(), out);
   if (bytes.size() >= 2 && bytes[0] == 'P') return DecodePnm(bytes.data(), bytes.size(), out);
-  return Error("'" + path + "': not a PNG or binary PNM file");
+  return Error("'" + path + "': not a PNG, JPEG or binary PNM file");
 }
 
 void ConvertChannels(const DecodedImage& in, int channels, DecodedImage* out) {

@@ -14,8 +14,8 @@
 //         libtca_hip.so, loaded at run time (--hip-lib or TCA_HIP_LIB).
 //
 // Images are PNG or binary PPM/PGM files (tca/image_io.h - OpenCV is not part of
-// this toolchain) or `--synthetic N` generated ones; `--decode-only` prints
-// geometry and a pixel hash per file and exits.
+// this toolchain), sequential JPEG files, or `--synthetic N` generated ones; `--decode-only` prints
+// geometry and a pixel hash per file and exits (`--dump DIR` also writes the decoded pixels there as PNM).
 //
 // Behavioural reference: `src/c++/examples/image_client.cc:85-276,537-702,1030-1052`.
 #include <dlfcn.h>
@@ -23,6 +23,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <deque>
+#include <fstream>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -435,7 +436,7 @@ class HipStage {
 };
 
 struct Options {
-  std::string model, version, hip_lib;
+  std::string model, version, hip_lib, dump_dir;
   size_t batch = 1, classes = 1, ring_depth = 4;
   Scale scale = Scale::NONE;
   bool async = false, hip = false, decode_only = false;
@@ -591,6 +592,7 @@ int main(int argc, char** argv) {
     else if (a == "-g") opt.device = std::atoi(value().c_str());
     else if (a == "--synthetic") opt.synthetic = std::atoi(value().c_str());
     else if (a == "--decode-only") opt.decode_only = true;
+    else if (a == "--dump") opt.dump_dir = value();
     else if (a == "--hip-lib") opt.hip_lib = value();
     else if (a == "--ring-depth") opt.ring_depth = std::max<size_t>(1, std::strtoul(value().c_str(), nullptr, 10));
     else if (a == "--preprocess") {
@@ -622,11 +624,19 @@ int main(int argc, char** argv) {
       uint64_t hash = 1469598103934665603ull;  // FNV-1a over the pixels
       for (uint8_t p : img.px) hash = (hash ^ p) * 1099511628211ull;
       std::cout << img.name << " " << img.h << " " << img.w << " " << img.c << " " << hash << std::endl;
+      if (!opt.dump_dir.empty()) {  // the decoded pixels as binary PGM / PPM, named after the file
+        const size_t slash = img.name.find_last_of('/');
+        const std::string base = slash == std::string::npos ? img.name : img.name.substr(slash + 1);
+        std::ofstream f(opt.dump_dir + "/" + base + (img.c == 1 ? ".pgm" : ".ppm"), std::ios::binary);
+        f << (img.c == 1 ? "P5" : "P6") << "\n" << img.w << " " << img.h << "\n255\n";
+        f.write(reinterpret_cast<const char*>(img.px.data()), static_cast<std::streamsize>(img.px.size()));
+        if (!f) FAIL("unable to write into '" << opt.dump_dir << "'");
+      }
     }
     return 0;
   }
   for (int i = 0; i < opt.synthetic; ++i) images.push_back(Synthetic(i));
-  if (images.empty()) FAIL("no images given (pass .png / .ppm files or --synthetic N)");
+  if (images.empty()) FAIL("no images given (pass .png / .jpg / .ppm files or --synthetic N)");
   if (opt.model.empty()) FAIL("-m <model name> is required");
   if (protocol == "grpc") {
     auto client = MakeGrpcClient(flags);

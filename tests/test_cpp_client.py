@@ -221,6 +221,104 @@ def test_cpp_png_reader_matches_pillow(built, tmp_path):
     assert p.returncode != 0 and "PNG" in (p.stdout + p.stderr)
 
 
+def _jpeg_photo(h, w, seed=5):
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([np.sin(x / 9.0) * 90 + 128 + y * 0.3, np.cos(y / 7.0 + x / 31.0) * 100 + 120, (x * y) % 251], -1)
+    img = img + rng.normal(0, 12, img.shape)
+    img[h // 4: h // 2, w // 3: w // 2] = [250, 10, 30]
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_cpp_jpeg_reader_matches_pillow(built, tmp_path):
+    """The JPEG decoder of the C++ library against Pillow (libjpeg-turbo, default settings) over chroma
+    subsampling modes, qualities, image sizes that are not multiples of the block size (down to 1x1), gray
+    files, optimised Huffman tables and restart intervals.  The decoder follows libjpeg's arithmetic, so the
+    pixels are expected to be equal; the assertion allows a difference of 1 for Pillow builds on another
+    libjpeg.  Progressive files are refused by name.  4:4:0 files (vertical-only subsampling) are not covered:
+    Pillow cannot write them - parity unpinned."""
+    import numpy as np
+    from PIL import Image
+
+    expected = {}
+    for (h, w) in [(64, 64), (37, 53), (1, 1), (3, 2), (8, 17), (121, 159), (16, 5)]:
+        im = Image.fromarray(_jpeg_photo(h, w))
+        for ss in (0, 1, 2):
+            for q in (30, 90):
+                path = str(tmp_path / f"c_{h}x{w}_s{ss}_q{q}.jpg")
+                im.save(path, quality=q, subsampling=ss)
+                expected[path] = None
+        path = str(tmp_path / f"g_{h}x{w}.jpg")
+        im.convert("L").save(path, quality=80)
+        expected[path] = None
+    im = Image.fromarray(_jpeg_photo(200, 300))
+    for name, kw in (("opt", {"optimize": True, "subsampling": 2}), ("rst", {"subsampling": 2, "restart_marker_blocks": 3}),
+                     ("rstrow", {"subsampling": 1, "restart_marker_rows": 1}), ("q100", {"quality": 100, "subsampling": 0})):
+        path = str(tmp_path / f"{name}.jpg")
+        im.save(path, **{"quality": 85, **kw})
+        expected[path] = None
+    for path in expected:
+        expected[path] = np.asarray(Image.open(path))
+    dump = tmp_path / "dump"
+    dump.mkdir()
+    out = _run([os.path.join(built, "image_client"), "--decode-only", "--dump", str(dump), *expected])
+    rows = {line.split()[0]: line.split()[1:] for line in out.strip().splitlines()}
+    assert set(rows) == set(expected)
+    exact = 0
+    for path, want in expected.items():
+        h, w = want.shape[:2]
+        c = 1 if want.ndim == 2 else 3
+        assert rows[path][:3] == [str(h), str(w), str(c)], path
+        raw = open(str(dump / (os.path.basename(path) + (".pgm" if c == 1 else ".ppm"))), "rb").read()
+        got = np.frombuffer(raw.split(b"\n", 3)[3], dtype=np.uint8).reshape(want.shape)
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1, path
+        exact += int(np.array_equal(got, want))
+    from PIL import features
+
+    if features.check_feature("libjpeg_turbo"):
+        assert exact == len(expected)
+    prog = str(tmp_path / "prog.jpg")
+    im.save(prog, quality=85, progressive=True)
+    p = subprocess.run([os.path.join(built, "image_client"), "--decode-only", prog], capture_output=True, text=True)
+    assert p.returncode != 0 and "progressive" in (p.stdout + p.stderr)
+    # damaged files end with a message, not a crash: truncated, and with bytes flipped all over the scan
+    data = open(str(tmp_path / "opt.jpg"), "rb").read()
+    rng = np.random.default_rng(3)
+    for k in range(24):
+        bad = bytearray(data[: len(data) - 1 - 40 * k] if k < 8 else data)
+        if k >= 8:
+            for at in rng.integers(2, len(bad) - 2, size=1 + k // 4):
+                bad[int(at)] ^= int(rng.integers(1, 256))
+        path = str(tmp_path / f"bad{k}.jpg")
+        open(path, "wb").write(bytes(bad))
+        p = subprocess.run([os.path.join(built, "image_client"), "--decode-only", path], capture_output=True, text=True)
+        assert p.returncode in (0, 1), (k, p.returncode, p.stderr[-300:])
+
+
+@pytest.mark.parametrize("protocol,mode", [("http", ()), ("grpc", ()), ("grpc", ("-a",))])
+def test_cpp_image_client_jpeg_files(built, server, tmp_path, protocol, mode):
+    """JPEG input over both protocols: the classes are the ones of the same pixels stored as PNG."""
+    import numpy as np
+    from PIL import Image
+
+    jpgs, pngs = [], []
+    for i in range(3):
+        path = str(tmp_path / f"img{i}.jpg")
+        Image.fromarray(_jpeg_photo(90 + 8 * i, 120, seed=20 + i)).save(path, quality=88, subsampling=2 - i)
+        jpgs.append(path)
+        png = str(tmp_path / f"img{i}.png")
+        Image.fromarray(np.asarray(Image.open(path))).save(png)
+        pngs.append(png)
+    url = server.http_url if protocol == "http" else server.grpc_url
+    common = ["-i", protocol, "-m", "tiny_classifier", "-b", "2", "-c", "2", "-s", "INCEPTION", *mode]
+    out = _run([os.path.join(built, "image_client"), "-u", url, *common, *jpgs])
+    ref = _run([os.path.join(built, "image_client"), "-u", url, *common, *pngs])
+    pick = lambda text: [line for line in text.splitlines() if line.startswith("    ")]  # noqa: E731
+    assert "PASS" in out and out.count("Image '") == 4 and pick(out) == pick(ref) and len(pick(out)) == 8
+
+
 @pytest.mark.parametrize("protocol,mode", [("http", ()), ("grpc", ()), ("grpc", ("-a",))])
 def test_cpp_image_client_png_files(built, server, tmp_path, protocol, mode):
     """PNG input over both protocols: same classes whatever the protocol / mode."""
