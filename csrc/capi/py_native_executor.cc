@@ -216,7 +216,8 @@ PyObject* Quiesce(PyObject* self_obj, PyObject*) {
 }
 
 // enable_graph_model(name, entry_points, device, streams, graphs, in_row_bytes, out_row_bytes, max_batch,
-//                    max_inflight, fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap)
+//                    max_inflight, fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap
+//                    [, host_arena, host_arena_bytes, host_chunk_bytes[, device_arena, copy_stream[, memcpy_async]]])
 // entry_points: addresses of (graph_launch, event_create, event_record, event_sync, event_destroy, set_device,
 // batched_copy); streams: one handle per execution instance; graphs: (instance, batch, exec, in_ptr, out_ptr).
 PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
@@ -224,9 +225,11 @@ PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
   const char* name = nullptr;
   PyObject *entry = nullptr, *streams = nullptr, *graphs = nullptr;
   int device = 0, max_batch = 0, max_inflight = 0, fill = 0, gap = 300, window = 100, split = 16, adaptive = 1;
-  unsigned long long in_row = 0, out_row = 0;
-  if (!PyArg_ParseTuple(args, "sOiOOKKiiiiiip", &name, &entry, &device, &streams, &graphs, &in_row, &out_row, &max_batch,
-                        &max_inflight, &fill, &gap, &window, &split, &adaptive))
+  unsigned long long in_row = 0, out_row = 0, arena = 0, arena_bytes = 0, chunk_bytes = 0, device_arena = 0, copy_stream = 0,
+                     memcpy_fn = 0;
+  if (!PyArg_ParseTuple(args, "sOiOOKKiiiiiip|KKKKKK", &name, &entry, &device, &streams, &graphs, &in_row, &out_row, &max_batch,
+                        &max_inflight, &fill, &gap, &window, &split, &adaptive, &arena, &arena_bytes, &chunk_bytes,
+                        &device_arena, &copy_stream, &memcpy_fn))
     return nullptr;
   tca::server::NativeExecutor::GraphPipe p;
   unsigned long long fn[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -274,6 +277,14 @@ PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
   p.burst_window_us = window;
   p.split_min_batch = split;
   p.adaptive_cap = adaptive != 0;
+  if (arena != 0 && arena_bytes != 0 && chunk_bytes != 0) {
+    p.host_arena = arena;
+    p.host_arena_bytes = arena_bytes;
+    p.host_chunk_bytes = chunk_bytes;
+    p.device_arena = device_arena;
+    p.copy_stream = reinterpret_cast<void*>(static_cast<uintptr_t>(copy_stream));
+    p.memcpy_async = reinterpret_cast<decltype(p.memcpy_async)>(static_cast<uintptr_t>(memcpy_fn));
+  }
   const std::string model(name);
   tca::Error e;
   Py_BEGIN_ALLOW_THREADS
@@ -317,9 +328,11 @@ PyObject* GraphStats(PyObject* self_obj, PyObject* args) {
   if (!PyArg_ParseTuple(args, "s", &name)) return nullptr;
   tca::server::NativeExecutor::GraphCounters c;
   if (!(*self->ex)->GraphStats(name, &c)) Py_RETURN_NONE;
-  return Py_BuildValue("{s:K,s:K,s:K,s:K}", "batches", static_cast<unsigned long long>(c.batches), "requests",
+  return Py_BuildValue("{s:K,s:K,s:K,s:K,s:K,s:K}", "batches", static_cast<unsigned long long>(c.batches), "requests",
                        static_cast<unsigned long long>(c.requests), "images", static_cast<unsigned long long>(c.images),
-                       "padded_images", static_cast<unsigned long long>(c.padded_images));
+                       "padded_images", static_cast<unsigned long long>(c.padded_images), "wire_requests",
+                       static_cast<unsigned long long>(c.wire_requests), "arena_full",
+                       static_cast<unsigned long long>(c.arena_full));
 }
 
 PyObject* RegisterDeviceRegion(PyObject* self_obj, PyObject* args) {
@@ -382,7 +395,9 @@ PyMethodDef kMethods[] = {
     {"quiesce", Quiesce, METH_NOARGS, "blocks until no deferred request is queued or running"},
     {"enable_graph_model", EnableGraphModel, METH_VARARGS,
      "enable_graph_model(name, entry_points, device, streams, graphs, in_row_bytes, out_row_bytes, max_batch, max_inflight, "
-     "fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap)"},
+     "fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap[, host_arena, host_arena_bytes, "
+     "host_chunk_bytes[, device_arena, copy_stream[, memcpy_async]]]): page-locked memory for requests with tensors inside the messages, and "
+     "device memory of the same size plus a stream for moving their inputs ahead of the batches"},
     {"disable_graph_model", DisableGraphModel, METH_VARARGS, "disable_graph_model([name]): answers what is queued and stops the threads"},
     {"begin_capture", BeginCapture, METH_NOARGS,
      "holds the batch threads' graph launches back (after those in progress) until end_capture(): a stream capture may run"},

@@ -342,22 +342,21 @@ void GrpcChannel::OpenCallStream(uint64_t id, Call* call) {
 }
 
 void GrpcChannel::SendMessage(uint64_t call_id, std::string&& serialized, bool last, bool compressed) {
-  std::string framed;
-  framed.reserve(serialized.size() + 5);
-  framed.push_back(compressed ? 1 : 0);
+  // The 5-byte message prefix travels as a DATA frame of its own in front of the message: a message may be
+  // split over frames any way, and this way a request of megabytes is not copied to put 5 bytes in front.
   const uint32_t n = static_cast<uint32_t>(serialized.size());
-  const char len[4] = {static_cast<char>(n >> 24), static_cast<char>(n >> 16), static_cast<char>(n >> 8),
-                       static_cast<char>(n)};
-  framed.append(len, 4);
-  framed.append(serialized);
-  pending_bytes_.fetch_add(framed.size());
-  auto shared = std::make_shared<std::string>(std::move(framed));
-  Post([this, call_id, shared, last] {
-    pending_bytes_.fetch_sub(shared->size());
+  const std::string prefix = {static_cast<char>(compressed ? 1 : 0), static_cast<char>(n >> 24), static_cast<char>(n >> 16),
+                              static_cast<char>(n >> 8), static_cast<char>(n)};
+  pending_bytes_.fetch_add(serialized.size() + 5);
+  auto shared = std::make_shared<std::string>(std::move(serialized));
+  Post([this, call_id, shared, last, prefix] {
+    pending_bytes_.fetch_sub(shared->size() + 5);
     auto it = calls_.find(call_id);
     if (it == calls_.end() || it->second.send_closed || !conn_) return;
     if (last) it->second.send_closed = true;
-    const Error e = conn_->SendData(it->second.stream, std::move(*shared), last);
+    const uint32_t stream = it->second.stream;
+    Error e = conn_->SendData(stream, std::string(prefix), false);
+    if (e.IsOk()) e = conn_->SendData(stream, std::move(*shared), last);
     if (!e.IsOk()) Finish(call_id, kGrpcInternal, e.Message());
   });
 }
@@ -448,14 +447,22 @@ void GrpcChannel::OnData(uint32_t stream, const uint8_t* data, size_t len, bool 
   if (end_stream) Finish(id, kGrpcUnknown, "stream closed without trailers");
 }
 
-void GrpcChannel::WriteSocket() {
-  while (conn_ && conn_->WantsWrite() && fd_ >= 0) {
+void GrpcChannel::WriteSocket(size_t budget) {
+  // `budget`: with tens of megabytes queued and a peer that keeps reading, this loop would not return for
+  // many milliseconds - and the responses waiting in the socket (whose callbacks issue the next requests)
+  // would wait with it.  The event loop comes straight back here after a look at the other direction.
+  size_t written = 0;
+  write_blocked_ = false;
+  while (conn_ && conn_->WantsWrite() && fd_ >= 0 && written < budget) {
     const std::string& out = conn_->Output();
     const size_t off = conn_->OutputOffset();
     ssize_t n;
     if (tls_) {
       n = tls_->Write(out.data() + off, out.size() - off);
-      if (n == net::TlsSession::kWouldBlock) return;  // the edge-triggered loop calls again on the next event
+      if (n == net::TlsSession::kWouldBlock) {  // the edge-triggered loop calls again on the next event
+        write_blocked_ = true;
+        return;
+      }
       if (n < 0) {
         const std::string why = tls_->LastError();  // Disconnect() destroys the session that owns the text
         Disconnect(why);
@@ -466,8 +473,10 @@ void GrpcChannel::WriteSocket() {
     }
     if (n > 0) {
       conn_->ConsumeOutput(static_cast<size_t>(n));
+      written += static_cast<size_t>(n);
       last_activity_ns_ = NowNs();
     } else if (n < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) {
+      write_blocked_ = true;
       return;  // EPOLLOUT (edge) fires when the socket drains
     } else if (n < 0 && errno == EINTR) {
       continue;
@@ -527,6 +536,7 @@ void GrpcChannel::Loop() {
       const int ms = left <= 0 ? 0 : static_cast<int>(left / 1000000) + 1;
       if (ms < timeout_ms) timeout_ms = ms;
     }
+    if (conn_ && conn_->WantsWrite() && !write_blocked_) timeout_ms = 0;  // more to send: only a look at the socket
     const int n = epoll_wait(epfd_, events, 8, timeout_ms);
     for (int i = 0; i < n; ++i) {
       if (events[i].data.fd == wake_fd_) {
@@ -566,7 +576,7 @@ void GrpcChannel::Loop() {
           Disconnect("keepalive watchdog timeout");
       }
     }
-    WriteSocket();
+    WriteSocket(4u << 20);
   }
   // shutting down: fail whatever is left
   std::vector<uint64_t> ids;

@@ -85,7 +85,10 @@ void Connection::ConsumeOutput(size_t n) {
   if (out_off_ >= out_.size()) {
     out_.clear();
     out_off_ = 0;
-  } else if (out_off_ > (1u << 20)) {  // keep the buffer from growing without bound behind a slow peer
+  } else if (out_off_ > (1u << 20) && out_off_ >= out_.size() / 2) {
+    // keep the buffer from growing without bound behind a slow peer - but only once the sent part is the
+    // larger one: dropping it moves the rest, and with tens of megabytes queued (many large messages on
+    // one connection) a move per megabyte sent costs many times the bytes sent
     out_.erase(0, out_off_);
     out_off_ = 0;
   }

@@ -123,7 +123,8 @@ class GrpcChannel {
   void Finish(uint64_t id, int status, std::string message);  // by value: callers pass fields of the call being erased
   void OnHeaders(uint32_t stream, h2::HeaderList&& headers, bool end_stream);
   void OnData(uint32_t stream, const uint8_t* data, size_t len, bool end_stream);
-  void WriteSocket();
+  void WriteSocket(size_t budget = static_cast<size_t>(-1));
+  bool write_blocked_ = false;  // the last send() found the socket full: EPOLLOUT will tell
   bool ReadSocket();
 
   const std::string url_;

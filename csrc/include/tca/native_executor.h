@@ -103,6 +103,22 @@ class NativeExecutor {
     int fill_window_us = 0, burst_gap_us = 300, burst_window_us = 100;
     int split_min_batch = 16;
     bool adaptive_cap = true;
+    // Requests whose tensors travel inside the messages: page-locked host memory that the device addresses too
+    // (the gather / scatter kernels read and write it over the bus).  A request's input bytes are copied into
+    // a piece of it by the thread that received the message, its output rows are taken from there into the
+    // response.  0 bytes: such requests take the general path.  Owned by the caller like the graphs.
+    uint64_t host_arena = 0, host_arena_bytes = 0;
+    uint64_t host_chunk_bytes = 1u << 20;  // allocation unit
+    // Optional second stage: device memory of the same size and a stream of its own.  A staging thread moves
+    // the input bytes of arriving requests from the host arena to the same offset of the device arena (one
+    // copy-kernel launch for everything that arrived meanwhile) before the requests join the batch queue, so
+    // the transfer over the bus overlaps the forward passes instead of running in front of them on the
+    // instances' streams.  Without it the gather kernel reads the host arena directly.
+    uint64_t device_arena = 0;
+    void* copy_stream = nullptr;
+    // When set, the staging thread moves each request's bytes with this (hipMemcpyAsync, host to device: the
+    // DMA engines, no compute unit involved) instead of the copy kernel.
+    int (*memcpy_async)(void* dst, const void* src, uint64_t bytes, int kind, void* stream) = nullptr;
   };
   // C entry points of the device BYTES pipeline (`csrc/hip/bytes_models.hip`) plus one pipeline
   // object and the stream its batches run on; all owned by the caller, alive until
@@ -160,8 +176,9 @@ class NativeExecutor {
   // Answers what is queued for `model` ("" = every graph model), then stops its threads.
   void DisableGraphModel(const std::string& model);
   // Batches launched, requests merged into them and rows computed beyond the merged batches (padding), per model.
+  // (wire_requests: requests of a graph model whose input or output travelled inside the messages)
   struct GraphCounters {
-    uint64_t batches = 0, requests = 0, images = 0, padded_images = 0;
+    uint64_t batches = 0, requests = 0, images = 0, padded_images = 0, wire_requests = 0, arena_full = 0;
   };
   bool GraphStats(const std::string& model, GraphCounters* out);
   // Stream capture elsewhere in the process (a model capturing one more graph) and graph launches from the
@@ -231,7 +248,8 @@ class NativeExecutor {
   struct GraphJob;
   class GraphRunner;
   friend class GraphRunner;
-  bool PrepareGraphJob(Request* req, const std::shared_ptr<Model>& model, const GraphRunner& runner, GraphJob* job);
+  bool PrepareGraphJob(Request* req, const std::shared_ptr<Model>& model, const std::shared_ptr<GraphRunner>& runner,
+                       GraphJob* job);
   std::shared_ptr<GraphRunner> FindRunner(const std::string& model);
   // Validates and queues a request for a graph model (`bytes`: the request message / body, moved on kDeferred).
   Outcome SubmitGraph(Request* req, const std::shared_ptr<Model>& model, std::string* bytes, Completion done,

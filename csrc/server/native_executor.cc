@@ -1133,6 +1133,11 @@ struct NativeExecutor::GraphJob {
   int batch = 1;
   uint64_t in_ptr = 0, out_ptr = 0;
   std::vector<std::shared_ptr<DeviceRegion>> leases;
+  // tensors inside the messages: a piece of the runner's host arena (input bytes first, output rows behind)
+  std::shared_ptr<GraphRunner> runner;
+  uint64_t host_ptr = 0, host_bytes = 0, host_out = 0, host_out_bytes = 0;
+  uint8_t* sys_out = nullptr;  // output window in a system shared-memory region (held by req.held): filled from host_out
+  uint64_t stage_bytes = 0;    // input bytes in the host arena that the staging thread moves to the device arena
   uint64_t t_queued = 0;
   uint64_t gap_ns = ~0ull >> 2;  // since the previous arrival for this model
 };
@@ -1148,7 +1153,11 @@ class NativeExecutor::GraphRunner {
     for (auto& inst : instances_)
       std::sort(inst->graphs.begin(), inst->graphs.end(), [](const GraphPipe::Graph& a, const GraphPipe::Graph& b) { return a.batch < b.batch; });
     cap_ = pipe_.max_inflight > 0 ? pipe_.max_inflight : 2 * static_cast<int>(instances_.size());
+    if (pipe_.host_arena != 0 && pipe_.host_chunk_bytes > 0)
+      chunk_used_.assign(static_cast<size_t>(pipe_.host_arena_bytes / pipe_.host_chunk_bytes), false);
     batch_thread_ = std::thread([this] { BatchLoop(); });
+    if (pipe_.device_arena != 0 && pipe_.copy_stream != nullptr && pipe_.host_arena != 0)
+      stage_thread_ = std::thread([this] { StageLoop(); });
     for (size_t i = 0; i < instances_.size(); ++i)
       instances_[i]->completer = std::thread([this, i] { CompleteLoop(static_cast<int>(i)); });
   }
@@ -1159,11 +1168,16 @@ class NativeExecutor::GraphRunner {
   bool Submit(std::unique_ptr<GraphJob>* job) {
     {
       std::lock_guard<std::mutex> lk(mu_);
-      if (stop_) return false;
+      if (stop_ || stage_stop_) return false;
       const uint64_t now = NowNs();
       (*job)->t_queued = now;
       (*job)->gap_ns = now - last_arrival_ns_;
       last_arrival_ns_ = now;
+      if ((*job)->stage_bytes != 0 && stage_thread_.joinable()) {
+        stage_queue_.push_back(std::move(*job));
+        stage_cv_.notify_one();
+        return true;
+      }
       queue_.push_back(std::move(*job));
     }
     cv_.notify_all();
@@ -1175,6 +1189,12 @@ class NativeExecutor::GraphRunner {
     {
       std::lock_guard<std::mutex> lk(mu_);
       if (stop_ && !batch_thread_.joinable()) return;
+      stage_stop_ = true;  // first the staging thread: what it holds still reaches the batch queue
+    }
+    stage_cv_.notify_all();
+    if (stage_thread_.joinable()) stage_thread_.join();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
       stop_ = true;
     }
     cv_.notify_all();
@@ -1190,16 +1210,50 @@ class NativeExecutor::GraphRunner {
       for (void* e : inst->free_events) pipe_.event_destroy(e);
       inst->free_events.clear();
     }
+    if (stage_event_ != nullptr) pipe_.event_destroy(stage_event_);
+    stage_event_ = nullptr;
   }
 
   void WaitIdle() {
     std::unique_lock<std::mutex> lk(mu_);
-    idle_cv_.wait(lk, [this] { return queue_.empty() && running_ == 0; });
+    idle_cv_.wait(lk, [this] { return queue_.empty() && running_ == 0 && stage_queue_.empty() && staging_ == 0; });
   }
 
   void Counters(GraphCounters* out) {
     std::lock_guard<std::mutex> lk(mu_);
     *out = counters_;
+    std::lock_guard<std::mutex> alk(arena_mu_);
+    out->wire_requests = wire_requests_;
+    out->arena_full = arena_full_;
+  }
+
+  // A piece of the host arena of at least `bytes` (whole chunks, first fit); 0 when nothing fits.
+  uint64_t AllocHost(uint64_t bytes) {
+    const uint64_t unit = pipe_.host_chunk_bytes;
+    const size_t want = static_cast<size_t>((bytes + unit - 1) / unit);
+    std::lock_guard<std::mutex> lk(arena_mu_);
+    const size_t n = chunk_used_.size();
+    if (want == 0 || want > n) return 0;
+    // next fit: start behind the previous allocation, requests are of similar size and short lived
+    for (size_t tried = 0, at = next_chunk_; tried < n; ++tried, at = (at + 1) % n) {
+      if (at + want > n) continue;
+      size_t k = 0;
+      while (k < want && !chunk_used_[at + k]) ++k;
+      if (k == want) {
+        for (k = 0; k < want; ++k) chunk_used_[at + k] = true;
+        next_chunk_ = (at + want) % n;
+        ++wire_requests_;
+        return pipe_.host_arena + static_cast<uint64_t>(at) * unit;
+      }
+    }
+    ++arena_full_;
+    return 0;
+  }
+  void FreeHost(uint64_t ptr, uint64_t bytes) {
+    const uint64_t unit = pipe_.host_chunk_bytes;
+    const size_t at = static_cast<size_t>((ptr - pipe_.host_arena) / unit), want = static_cast<size_t>((bytes + unit - 1) / unit);
+    std::lock_guard<std::mutex> lk(arena_mu_);
+    for (size_t k = 0; k < want && at + k < chunk_used_.size(); ++k) chunk_used_[at + k] = false;
   }
 
  private:
@@ -1224,6 +1278,62 @@ class NativeExecutor::GraphRunner {
     int m = instances_[0]->busy;
     for (const auto& inst : instances_) m = std::min(m, inst->busy);
     return m;
+  }
+
+  // Input bytes of requests that arrived inside messages (or in system shared memory) go from the host arena
+  // to the device arena here, everything that arrived since the previous round in one copy-kernel launch on
+  // the copy stream; the requests join the batch queue once their bytes are on the device.
+  void StageLoop() {
+    if (pipe_.set_device != nullptr) pipe_.set_device(pipe_.device);
+    std::vector<const void*> srcs;
+    std::vector<void*> dsts;
+    std::vector<uint64_t> bytes;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      stage_cv_.wait(lk, [this] { return stage_stop_ || !stage_queue_.empty(); });
+      if (stage_queue_.empty()) return;
+      std::vector<std::unique_ptr<GraphJob>> round;
+      while (!stage_queue_.empty()) {
+        round.push_back(std::move(stage_queue_.front()));
+        stage_queue_.pop_front();
+      }
+      staging_ += round.size();
+      lk.unlock();
+      srcs.clear();
+      dsts.clear();
+      bytes.clear();
+      for (auto& job : round) {
+        srcs.push_back(reinterpret_cast<const void*>(static_cast<uintptr_t>(job->host_ptr)));
+        dsts.push_back(reinterpret_cast<void*>(static_cast<uintptr_t>(pipe_.device_arena + (job->host_ptr - pipe_.host_arena))));
+        bytes.push_back(job->stage_bytes);
+      }
+      int rc = 0;
+      if (stage_event_ == nullptr) rc = pipe_.event_create(&stage_event_);
+      owner_->EnterLaunch();
+      if (rc == 0 && pipe_.memcpy_async != nullptr) {
+        for (size_t i = 0; i < round.size() && rc == 0; ++i)
+          rc = pipe_.memcpy_async(dsts[i], srcs[i], bytes[i], 1 /* host to device */, pipe_.copy_stream);
+      } else if (rc == 0) {
+        rc = pipe_.batched_copy(srcs.data(), dsts.data(), bytes.data(), static_cast<int>(round.size()), pipe_.copy_stream);
+      }
+      if (rc == 0) rc = pipe_.event_record(stage_event_, pipe_.copy_stream);
+      owner_->LeaveLaunch();
+      if (rc == 0) rc = pipe_.event_sync(stage_event_);
+      if (rc != 0) {  // the requests take the general path
+        for (auto& job : round) owner_->FinishGraphJob(job.get(), false, 0, 0, 0, false);
+        lk.lock();
+        staging_ -= round.size();
+        if (queue_.empty() && running_ == 0 && stage_queue_.empty() && staging_ == 0) idle_cv_.notify_all();
+        continue;
+      }
+      lk.lock();
+      staging_ -= round.size();
+      for (auto& job : round) {
+        job->in_ptr = pipe_.device_arena + (job->host_ptr - pipe_.host_arena);
+        queue_.push_back(std::move(job));
+      }
+      cv_.notify_all();
+    }
   }
 
   // The serving policy of the dynamic batcher (server/batcher.py: _next_group), on one lock:
@@ -1382,7 +1492,7 @@ class NativeExecutor::GraphRunner {
       --inst.busy;
       --inflight_;
       running_ -= group.size();
-      if (queue_.empty() && running_ == 0) idle_cv_.notify_all();
+      if (queue_.empty() && running_ == 0 && stage_queue_.empty() && staging_ == 0) idle_cv_.notify_all();
       return;
     }
     lk->lock();
@@ -1429,7 +1539,7 @@ class NativeExecutor::GraphRunner {
       }
       lk.lock();
       running_ -= l.jobs.size();
-      if (queue_.empty() && running_ == 0) idle_cv_.notify_all();
+      if (queue_.empty() && running_ == 0 && stage_queue_.empty() && staging_ == 0) idle_cv_.notify_all();
     }
   }
 
@@ -1447,6 +1557,16 @@ class NativeExecutor::GraphRunner {
   size_t last_done_requests_ = 1, running_ = 0;
   GraphCounters counters_;
   std::thread batch_thread_;
+  std::thread stage_thread_;
+  std::condition_variable stage_cv_;
+  std::deque<std::unique_ptr<GraphJob>> stage_queue_;
+  size_t staging_ = 0;
+  bool stage_stop_ = false;
+  void* stage_event_ = nullptr;
+  std::mutex arena_mu_;
+  std::vector<bool> chunk_used_;
+  size_t next_chunk_ = 0;
+  uint64_t wire_requests_ = 0, arena_full_ = 0;
   std::vector<const void*> srcs_;  // scratch of the batch thread
   std::vector<void*> dsts_;
   std::vector<uint64_t> bytes_;
@@ -1548,16 +1668,35 @@ bool NativeExecutor::GraphStats(const std::string& model, GraphCounters* out) {
 
 // Validates a request for a graph model as far as the general path would before it queues the request,
 // and takes the leases on its regions.  False = not ours (the general path serves it, or words the error).
-bool NativeExecutor::PrepareGraphJob(Request* req, const std::shared_ptr<Model>& model, const GraphRunner& runner,
-                                     GraphJob* job) {
+bool NativeExecutor::PrepareGraphJob(Request* req, const std::shared_ptr<Model>& model,
+                                     const std::shared_ptr<GraphRunner>& runner, GraphJob* job) {
   const ModelSpec& spec = model->spec;
-  const GraphPipe& pipe = runner.pipe();
-  if (req->has_sequence || req->inputs.size() != 1 || req->outputs.size() != 1) return false;  // the output must name its region
+  const GraphPipe& pipe = runner->pipe();
+  if (req->has_sequence || req->inputs.size() != 1 || req->outputs.size() > 1) return false;
   const Request::Input& in = req->inputs[0];
-  const Request::Output& out = req->outputs[0];
   const TensorSpec& ts = spec.inputs[0];
-  if (in.name != ts.name || in.datatype != ts.datatype || !in.shm.set || in.has_data) return false;
-  if (out.name != spec.outputs[0].name || !out.shm.set) return false;
+  if (in.name != ts.name || in.datatype != ts.datatype) return false;
+  // either side in a registered device region, or in host memory - inside the message or in a system
+  // shared-memory region - and then through the host arena
+  const bool out_named = !req->outputs.empty();
+  if (in.shm.set == in.has_data) return false;
+  if (out_named && req->outputs[0].name != spec.outputs[0].name) return false;
+  std::shared_ptr<Region> in_sys, out_sys;
+  {
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    if (in.shm.set && device_regions_.find(in.shm.region) == device_regions_.end()) {
+      auto it = regions_.find(in.shm.region);
+      if (it != regions_.end()) in_sys = it->second;
+    }
+    if (out_named && req->outputs[0].shm.set && device_regions_.find(req->outputs[0].shm.region) == device_regions_.end()) {
+      auto it = regions_.find(req->outputs[0].shm.region);
+      if (it != regions_.end()) out_sys = it->second;
+    }
+  }
+  const bool in_wire = !in.shm.set || in_sys != nullptr;
+  const bool out_wire = !out_named || !req->outputs[0].shm.set || out_sys != nullptr;
+  if (out_named && !req->outputs[0].shm.set && !req->outputs[0].binary) return false;  // HTTP: rows as JSON numbers
+  if ((in_wire || out_wire) && pipe.host_arena == 0) return false;
   if (in.shape.size() != ts.dims.size() + 1) return false;
   for (size_t d = 0; d < ts.dims.size(); ++d)
     if (in.shape[d + 1] != ts.dims[d]) return false;
@@ -1565,8 +1704,26 @@ bool NativeExecutor::PrepareGraphJob(Request* req, const std::shared_ptr<Model>&
   if (batch < 1 || batch > spec.max_batch || batch > pipe.max_batch) return false;
   const uint64_t in_need = static_cast<uint64_t>(batch) * pipe.in_row_bytes;
   const uint64_t out_need = static_cast<uint64_t>(batch) * pipe.out_row_bytes;
-  if (in.shm.offset < 0 || out.shm.offset < 0 || in.shm.size < 0 || out.shm.size < 0) return false;
-  if (static_cast<uint64_t>(in.shm.size) < in_need || static_cast<uint64_t>(out.shm.size) < out_need) return false;
+  const uint8_t* in_bytes = in.data;
+  if (in_sys) {
+    if (in.shm.offset < 0 || static_cast<uint64_t>(in.shm.size) != in_need ||
+        static_cast<uint64_t>(in.shm.offset) + in_need > in_sys->size)
+      return false;
+    in_bytes = in_sys->base + in.shm.offset;
+  } else if (in_wire && in.size != in_need) {
+    return false;  // the general path words the error
+  }
+  if (out_sys) {
+    const ShmRef& ref = req->outputs[0].shm;
+    if (ref.offset < 0 || ref.size < 0 || static_cast<uint64_t>(ref.size) < out_need ||
+        static_cast<uint64_t>(ref.offset) + static_cast<uint64_t>(ref.size) > out_sys->size)
+      return false;
+  }
+  const ShmRef none;
+  const ShmRef& in_shm = in.shm;
+  const ShmRef& out_shm = out_named ? req->outputs[0].shm : none;
+  if (!in_wire && (in_shm.offset < 0 || in_shm.size < 0 || static_cast<uint64_t>(in_shm.size) < in_need)) return false;
+  if (!out_wire && (out_shm.offset < 0 || out_shm.size < 0 || static_cast<uint64_t>(out_shm.size) < out_need)) return false;
   {
     std::shared_lock<std::shared_mutex> lk(mu_);
     auto lease = [&](const ShmRef& ref, uint64_t need, uint64_t* address) {
@@ -1581,20 +1738,45 @@ bool NativeExecutor::PrepareGraphJob(Request* req, const std::shared_ptr<Model>&
       job->leases.push_back(it->second);
       return true;
     };
-    if (!lease(in.shm, in_need, &job->in_ptr) || !lease(out.shm, out_need, &job->out_ptr)) {
+    if ((!in_wire && !lease(in_shm, in_need, &job->in_ptr)) || (!out_wire && !lease(out_shm, out_need, &job->out_ptr))) {
       for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
       job->leases.clear();
       return false;
     }
   }
+  if (in_wire || out_wire) {
+    const uint64_t in_part = in_wire ? (in_need + 255) / 256 * 256 : 0;
+    job->host_bytes = in_part + (out_wire ? out_need : 0);
+    job->host_ptr = runner->AllocHost(job->host_bytes);
+    if (job->host_ptr == 0) {  // every piece is taken: the general path has its own staging
+      for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
+      job->leases.clear();
+      return false;
+    }
+    job->runner = runner;
+    if (in_wire) {
+      std::memcpy(reinterpret_cast<void*>(static_cast<uintptr_t>(job->host_ptr)), in_bytes, in_need);
+      job->in_ptr = job->host_ptr;  // the staging thread, when there is one, points it at the device arena
+      job->stage_bytes = in_need;
+    }
+    if (out_wire) {
+      job->host_out = job->host_ptr + in_part;
+      job->host_out_bytes = out_need;
+      job->out_ptr = job->host_out;
+    }
+    if (out_sys) {  // stays mapped until the answer is built, whatever happens to the registration
+      job->sys_out = out_sys->base + req->outputs[0].shm.offset;
+      req->held.push_back(out_sys);
+    }
+  }
   job->batch = static_cast<int>(batch);
   req->results.clear();
   Result r;
-  r.name = out.name;
+  r.name = spec.outputs[0].name;
   r.datatype = spec.outputs[0].datatype;
   r.shape.push_back(batch);
   for (int64_t d : spec.outputs[0].dims) r.shape.push_back(d);
-  r.shm = out.shm;
+  if (!out_wire || out_sys) r.shm = out_shm;
   req->results.push_back(std::move(r));
   req->version_used = spec.version;
   return true;
@@ -1604,7 +1786,7 @@ NativeExecutor::Outcome NativeExecutor::SubmitGraph(Request* req, const std::sha
                                                     Completion done, HttpCompletion http_done) {
   std::shared_ptr<GraphRunner> runner = FindRunner(model->spec.name);
   auto job = std::make_unique<GraphJob>();
-  if (!runner || !PrepareGraphJob(req, model, *runner, job.get())) {
+  if (!runner || !PrepareGraphJob(req, model, runner, job.get())) {
     declined_.fetch_add(1, std::memory_order_relaxed);
     return Outcome::kDeclined;
   }
@@ -1616,6 +1798,7 @@ NativeExecutor::Outcome NativeExecutor::SubmitGraph(Request* req, const std::sha
   job->http_done = std::move(http_done);
   if (!runner->Submit(&job)) {  // stopping: hand the request back untouched
     *bytes = std::move(job->request_bytes);
+    if (job->host_ptr != 0) runner->FreeHost(job->host_ptr, job->host_bytes);
     for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
     declined_.fetch_add(1, std::memory_order_relaxed);
     return Outcome::kDeclined;
@@ -1629,6 +1812,12 @@ void NativeExecutor::FinishGraphJob(GraphJob* job, bool ok, uint64_t t_exec, uin
   HeaderList headers;
   std::vector<std::string> parts;
   if (ok) {
+    if (job->sys_out != nullptr)  // output rows belong in a system shared-memory region
+      std::memcpy(job->sys_out, reinterpret_cast<const void*>(static_cast<uintptr_t>(job->host_out)),
+                  static_cast<size_t>(job->host_out_bytes));
+    else if (job->host_out != 0)  // ... or travel inside the response
+      job->req.results[0].bytes.assign(reinterpret_cast<const char*>(static_cast<uintptr_t>(job->host_out)),
+                                       static_cast<size_t>(job->host_out_bytes));
     if (job->http_done) BuildHttpResponse(job->req, &job->req.results, &headers, &parts);
     else BuildGrpcResponse(job->req, job->req.results, -1, &payload);
     const uint64_t now = NowNs();
@@ -1652,6 +1841,11 @@ void NativeExecutor::FinishGraphJob(GraphJob* job, bool ok, uint64_t t_exec, uin
   // the regions are free again before the caller hears about it: it may unregister them right away
   for (auto& r : job->leases) r->inflight.fetch_sub(1, std::memory_order_acq_rel);
   job->leases.clear();
+  if (job->host_ptr != 0) {
+    job->runner->FreeHost(job->host_ptr, job->host_bytes);
+    job->host_ptr = 0;
+    job->runner.reset();
+  }
   if (job->http_done) {
     if (!ok) parts.assign(1, std::move(payload));
     job->http_done(ok, std::move(headers), std::move(parts));

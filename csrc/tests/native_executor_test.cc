@@ -544,6 +544,34 @@ int FakeBatchedCopy(const void* const* srcs, void* const* dsts, const uint64_t* 
   return 0;
 }
 
+// Tensors inside the message: `in` travels as raw contents; the output comes back inside the response
+// (`out_region` empty) or goes to the region.
+std::string GraphWireRequest(const float* in, int batch, const std::string& out_region, int64_t out_off, int64_t out_size) {
+  std::string out;
+  pb::Writer w(&out);
+  w.String(1, "classifier");
+  w.String(3, "g-7");
+  std::string t, shape;
+  pb::Writer tw(&t), sw(&shape);
+  tw.String(1, "input");
+  tw.String(2, "FP32");
+  sw.Varint(static_cast<uint64_t>(batch));
+  sw.Varint(4);
+  tw.Message(3, shape);
+  w.Message(5, t);
+  if (!out_region.empty()) {
+    std::string o;
+    pb::Writer ow(&o);
+    ow.String(1, "output");
+    Param(&ow, 2, "shared_memory_region", &out_region, 0);
+    Param(&ow, 2, "shared_memory_byte_size", nullptr, out_size);
+    Param(&ow, 2, "shared_memory_offset", nullptr, out_off);
+    w.Message(6, o);
+  }
+  w.Bytes(7, in, static_cast<size_t>(batch) * 16);
+  return out;
+}
+
 std::string GraphRequest(const std::string& region, int batch, int64_t in_off, int64_t out_off, int64_t out_size,
                          bool name_output = true) {
   std::string out;
@@ -608,6 +636,17 @@ void GraphPath() {
   pipe.max_batch = 16;
   pipe.fill_window_us = 200;
   pipe.split_min_batch = 4;
+  // "page-locked" memory for tensors inside messages: 5 pieces of 256 bytes - too few for six threads, so
+  // some requests find it taken and take the general path
+  std::vector<uint8_t> arena(5 * 256 + 256);
+  pipe.host_arena = (reinterpret_cast<uintptr_t>(arena.data()) + 255) / 256 * 256;
+  pipe.host_arena_bytes = 5 * 256;
+  pipe.host_chunk_bytes = 256;
+  // ... moved on to "device" memory by the staging thread on a stream of its own
+  std::vector<uint8_t> device_arena(5 * 256 + 256);
+  FakeStream copy_stream;
+  pipe.device_arena = (reinterpret_cast<uintptr_t>(device_arena.data()) + 255) / 256 * 256;
+  pipe.copy_stream = &copy_stream;
   for (int inst = 0; inst < 2; ++inst)
     for (int b : {1, 2, 4, 8, 16}) {
       graphs.emplace_back(new FakeGraph());
@@ -636,9 +675,11 @@ void GraphPath() {
   if (!ex.RegisterDeviceRegion("dev", reinterpret_cast<uint64_t>(base), kThreads * kSlot, 0).IsOk())
     Fail("graph: registering the region");
   {
-    std::string no_out = GraphRequest("dev", 2, 0, 256, 64, false);
-    if (ex.TryGrpcAsync(&no_out, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
-      Fail("graph: an output without a region must take the general path");
+    const float two_rows[12] = {0};
+    std::string short_raw = GraphWireRequest(two_rows, 3, "", 0, 0);  // says 3 rows ...
+    short_raw.resize(short_raw.size() - 16);                              // ... (and the length prefix is off now)
+    if (ex.TryGrpcAsync(&short_raw, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
+      Fail("graph: a damaged message must take the general path");
     std::string tiny = GraphRequest("dev", 4, 0, 256, 16);
     if (ex.TryGrpcAsync(&tiny, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
       Fail("graph: an output range that cannot hold the result must take the general path");
@@ -649,8 +690,15 @@ void GraphPath() {
     if (ex.TryGrpcAsync(&big, &response, [](bool, std::string&&) {}) != NativeExecutor::Outcome::kDeclined)
       Fail("graph: a batch beyond the model's limit must take the general path");
   }
+  // a system shared-memory region with the same per-thread windows
+  const char* sys_key = "/tca_native_graph_test";
+  shm_unlink(sys_key);
+  const int sys_fd = shm_open(sys_key, O_CREAT | O_RDWR, 0600);
+  if (sys_fd < 0 || ftruncate(sys_fd, kThreads * kSlot) != 0) Fail("graph: creating the system region");
+  uint8_t* sys_base = static_cast<uint8_t*>(mmap(nullptr, kThreads * kSlot, PROT_READ | PROT_WRITE, MAP_SHARED, sys_fd, 0));
+  if (sys_base == MAP_FAILED || !ex.RegisterRegion("sys", sys_key, 0, kThreads * kSlot).IsOk()) Fail("graph: registering the system region");
   std::atomic<bool> stop{false};
-  std::atomic<long> answered{0}, refused{0}, declined{0}, images{0};
+  std::atomic<long> answered{0}, refused{0}, declined{0}, images{0}, wire_answers{0}, sys_answers{0};
   std::vector<std::thread> workers;
   for (int t = 0; t < kThreads; ++t) {
     workers.emplace_back([&, t] {
@@ -664,7 +712,18 @@ void GraphPath() {
         for (int i = 0; i < batch * 4; ++i) in[i] = static_cast<float>((round * 131 + i * 7 + t * 1009) % 4001) - 2000.f;
         std::memcpy(slot, in, static_cast<size_t>(batch) * 16);
         std::memset(slot + 256, 0xEE, 64);
-        std::string request = GraphRequest("dev", batch, static_cast<int64_t>(t) * kSlot, static_cast<int64_t>(t) * kSlot + 256, 64);
+        // a third of the requests carry the input inside the message, half of those the output too
+        // ... and every fifth request has both tensors in the system region
+        const int form = round % 5 == 4 ? 3 : round % 3 == 1 ? 1 + (round / 3) % 2 : 0;
+        uint8_t* sys_slot = sys_base + static_cast<size_t>(t) * kSlot;
+        if (form == 3) {
+          std::memcpy(sys_slot, in, static_cast<size_t>(batch) * 16);
+          std::memset(sys_slot + 256, 0xEE, 64);
+        }
+        std::string request =
+            form == 0 ? GraphRequest("dev", batch, static_cast<int64_t>(t) * kSlot, static_cast<int64_t>(t) * kSlot + 256, 64)
+            : form == 3 ? GraphRequest("sys", batch, static_cast<int64_t>(t) * kSlot, static_cast<int64_t>(t) * kSlot + 256, 64)
+                        : GraphWireRequest(in, batch, form == 1 ? "" : "dev", static_cast<int64_t>(t) * kSlot + 256, 64);
         const std::string copy = request;
         bool done = false, ok = false;
         std::string payload;
@@ -694,7 +753,20 @@ void GraphPath() {
           continue;
         }
         float out[16];
-        std::memcpy(out, slot + 256, static_cast<size_t>(batch) * 8);
+        if (form == 1) {
+          const auto raws = RawOutputs(payload);
+          if (raws.size() != 1 || raws[0].size() != static_cast<size_t>(batch) * 8) {
+            Fail("graph: a response without its output rows");
+            continue;
+          }
+          std::memcpy(out, raws[0].data(), raws[0].size());
+          ++wire_answers;
+        } else if (form == 3) {
+          std::memcpy(out, sys_slot + 256, static_cast<size_t>(batch) * 8);
+          ++sys_answers;
+        } else {
+          std::memcpy(out, slot + 256, static_cast<size_t>(batch) * 8);
+        }
         for (int r = 0; r < batch; ++r) {
           const float* x = in + r * 4;
           if (out[2 * r] != x[0] + x[1] + x[2] + x[3] + 1.0f || out[2 * r + 1] != 2.0f * x[0]) {
@@ -736,6 +808,13 @@ void GraphPath() {
   long launches = 0;
   for (const auto& g : graphs) launches += g->launches.load();
   if (static_cast<uint64_t>(launches) != counters.batches) Fail("graph: launches counted do not match the graphs' own count");
+  if (sys_answers.load() == 0) Fail("graph: no request with tensors in system shared memory was served");
+  ex.UnregisterRegion("sys");
+  munmap(sys_base, kThreads * kSlot);
+  close(sys_fd);
+  shm_unlink(sys_key);
+  if (wire_answers.load() == 0 || counters.wire_requests < static_cast<uint64_t>(wire_answers.load()) || counters.arena_full == 0)
+    Fail("graph: requests with tensors inside the messages were not served, or the staging memory never ran out");
   // a request queued while the model goes away is answered or handed back, never dropped
   {
     std::atomic<int> verdicts{0};

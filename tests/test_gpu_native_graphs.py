@@ -145,3 +145,102 @@ def test_general_path_agrees(reference):
     xs, refs = reference
     metrics, _ = _serve_and_check({"TCA_NATIVE_GRAPHS": "0"}, xs, refs, "grpc")
     assert _metric(metrics, 'tca_native_graph_batches_total{model="resnet50"}') is None
+
+
+@pytest.mark.parametrize("protocol", ["grpc", "http"])
+def test_tensors_inside_the_messages_are_served_natively(reference, protocol):
+    """Requests that carry the input inside the message and get the output rows back inside the response,
+    the two mixed forms (input in a device region / output in the response, input in the message / output in
+    a device region) and requests with both tensors in system shared memory run from the same graphs:
+    staged through page-locked memory, no interpreter, same answers."""
+    import tritonclient.grpc as g
+    import tritonclient.http as h
+    import tritonclient.utils.cuda_shared_memory as hipshm
+
+    from triton_client_amd.server import spawn_server
+
+    import tritonclient.utils.shared_memory as sysshm
+
+    xs, refs = reference
+    n = 24
+    srv = spawn_server(models=["resnet50"], gpu=0)
+    regions, sys_regions = [], {}
+    try:
+        mod = g if protocol == "grpc" else h
+        url = srv.grpc_url if protocol == "grpc" else srv.http_url
+        kwargs = {} if protocol == "grpc" else {"concurrency": 16}
+        with mod.InferenceServerClient(url, **kwargs) as c:
+            for i in range(n):
+                b = BATCHES[i]
+                hin = hipshm.create_shared_memory_region(f"nw_in{i}", b * ROW_IN, 0)
+                hout = hipshm.create_shared_memory_region(f"nw_out{i}", b * ROW_OUT, 0)
+                hipshm.set_shared_memory_region(hin, [xs[i]])
+                c.register_cuda_shared_memory(f"nw_in{i}", hipshm.get_raw_handle(hin), 0, b * ROW_IN)
+                c.register_cuda_shared_memory(f"nw_out{i}", hipshm.get_raw_handle(hout), 0, b * ROW_OUT)
+                regions.append((hin, hout))
+                if i % 4 == 3:
+                    hs = sysshm.create_shared_memory_region(f"nw_sys{i}", f"/tca_nw_sys{i}", b * (ROW_IN + ROW_OUT))
+                    sysshm.set_shared_memory_region(hs, [xs[i]])
+                    c.register_system_shared_memory(f"nw_sys{i}", f"/tca_nw_sys{i}", b * (ROW_IN + ROW_OUT))
+                    sys_regions[i] = hs
+
+            def request(i):
+                # 0: both inside the messages, 1: device region in / wire out, 2: wire in / device region out,
+                # 3: both in system shared memory
+                b, form = BATCHES[i], i % 4
+                inp = mod.InferInput("input", [b, 3, 224, 224], "FP16")
+                if form == 1:
+                    inp.set_shared_memory(f"nw_in{i}", b * ROW_IN)
+                elif form == 3:
+                    inp.set_shared_memory(f"nw_sys{i}", b * ROW_IN)
+                else:
+                    inp.set_data_from_numpy(xs[i])
+                out = mod.InferRequestedOutput("output")
+                if form == 2:
+                    out.set_shared_memory(f"nw_out{i}", b * ROW_OUT)
+                elif form == 3:
+                    out.set_shared_memory(f"nw_sys{i}", b * ROW_OUT, offset=b * ROW_IN)
+                return [inp], [out]
+
+            results = [None] * n
+            for _ in range(2):
+                if protocol == "grpc":
+                    done = queue.Queue()
+                    for i in range(n):
+                        ins, outs = request(i)
+                        c.async_infer("resnet50", ins, lambda result, error, i=i: done.put((i, result, error)), outputs=outs)
+                    for _ in range(n):
+                        i, result, error = done.get(timeout=120)
+                        assert error is None, error
+                        results[i] = result
+                else:
+                    pending = [(i, c.async_infer("resnet50", request(i)[0], outputs=request(i)[1])) for i in range(n)]
+                    for i, p in pending:
+                        results[i] = p.get_result(timeout=120)
+            outs = []
+            for i in range(n):
+                if i % 4 == 2:
+                    outs.append(np.array(hipshm.get_contents_as_numpy(regions[i][1], np.float32, [BATCHES[i], 1000]), copy=True))
+                elif i % 4 == 3:
+                    outs.append(np.array(sysshm.get_contents_as_numpy(sys_regions[i], np.float32, [BATCHES[i], 1000],
+                                                                      offset=BATCHES[i] * ROW_IN), copy=True))
+                else:
+                    outs.append(results[i].as_numpy("output"))
+            c.unregister_cuda_shared_memory()
+            c.unregister_system_shared_memory()
+        with urllib.request.urlopen(f"http://{srv.http_url}/metrics", timeout=30) as resp:
+            metrics = resp.read().decode()
+    finally:
+        srv.stop()
+        for hin, hout in regions:
+            hipshm.destroy_shared_memory_region(hin)
+            hipshm.destroy_shared_memory_region(hout)
+        for hs in sys_regions.values():
+            sysshm.destroy_shared_memory_region(hs)
+    scale = max(float(np.abs(r).max()) for r in refs[:n])
+    worst = max(float(np.abs(o - r).max()) for o, r in zip(outs, refs[:n]))
+    assert all(o.shape == r.shape for o, r in zip(outs, refs[:n])) and worst < 2e-2 * scale, (worst, scale)
+    assert _metric(metrics, 'tca_native_graph_requests_total{model="resnet50"}') == 2 * n  # none took the general path
+    assert _metric(metrics, 'tca_native_graph_wire_requests_total{model="resnet50"}') == 2 * n
+    assert _metric(metrics, 'tca_native_graph_arena_full_total{model="resnet50"}') == 0
+    assert _metric(metrics, 'tca_graph_captures_online_total{model="resnet50"}') == 0

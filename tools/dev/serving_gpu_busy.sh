@@ -25,7 +25,7 @@ except Exception:
 PY
     sleep 2
 done
-TCA_PERF_CONNECTIONS=8 timeout -k 10 120 python3 -m triton_client_amd.perf -m resnet50 -u 127.0.0.1:18201 -i grpc -b 8 --shared-memory hip \
+TCA_PERF_CONNECTIONS=8 timeout -k 10 120 python3 -m triton_client_amd.perf -m resnet50 -u 127.0.0.1:18201 -i grpc -b 8 --shared-memory ${SHM:-hip} \
     --concurrency-range ${CONC:-64}:${CONC:-64} --native -p 1500 --stability-windows 2 > "$OUT/busy_perf.txt" 2>&1
 RC=$?
 kill $HOLD 2>/dev/null
@@ -33,12 +33,12 @@ wait $SRV
 rm -f /tmp/srv_stdin3
 tail -3 "$OUT/busy_perf.txt"
 [ $RC -eq 0 ] || { tail -20 "$OUT/busy.err"; exit 1; }
-python3 - "$(find "$OUT/busy" -name '*kernel_trace.csv' | head -1)" "$SUM/serving_gpu_busy.txt" <<'PY'
+python3 - "$(find "$OUT/busy" -name '*kernel_trace.csv' | head -1)" "$SUM/serving_gpu_busy_${SHM:-hip}.txt" <<'PY'
 import csv, sys
 rows = []
 with open(sys.argv[1]) as fh:
     for r in csv.DictReader(fh):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:90]))
 rows.sort()
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 # the load ran at the end of the trace: the last 2.5 s, minus the final half second
@@ -64,6 +64,21 @@ text = (f"window {wall / 1e6:.0f} ms, {len(sel)} kernels\n"
         f"mean kernels executing at once: {total / wall:.2f}\n"
         f"idle gaps: {len(gaps)}, total {sum(gaps) / 1e6:.1f} ms, median {gaps[len(gaps) // 2] / 1e3 if gaps else 0:.1f} us, "
         f"p99 {gaps[int(len(gaps) * 0.99)] / 1e3 if gaps else 0:.1f} us, longest {gaps[-1] / 1e3 if gaps else 0:.1f} us\n")
+# time per kernel family over the window (copy kernels: gathers, scatters and the staging of host tensors)
+fam = {}
+for s, e, name in rows:
+    if e > lo and s < hi:
+        key = name.split("(")[0].split("<")[0][:40]
+        d = fam.setdefault(key, [0, 0])
+        d[0] += 1
+        d[1] += min(e, hi) - max(s, lo)
+for key, (n, ns) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:8]:
+    text += f"  {key:40s} {n:7d} launches, {ns / 1e6:8.1f} ms in flight ({100.0 * ns / wall:5.1f} % of the window), mean {ns / n / 1e3:7.1f} us\n"
+copies = sorted(e - s for s, e, name in rows if e > lo and s < hi and "BatchedCopy" in name)
+if copies:
+    pick = lambda q: copies[min(len(copies) - 1, int(len(copies) * q))] / 1e3
+    text += (f"copy kernels: {len(copies)} launches, p10 {pick(0.1):.1f} / p50 {pick(0.5):.1f} / p90 {pick(0.9):.1f} / "
+             f"max {copies[-1] / 1e3:.1f} us; over 100 us: {sum(1 for c in copies if c > 100_000)}\n")
 open(sys.argv[2], "w").write(text)
 print(text)
 PY

@@ -52,9 +52,11 @@ class Server:
         # additionally requires client certificates signed by that CA (mutual TLS)
         self._tls = (tls_cert, tls_key, tls_client_ca) if tls_cert and tls_key else None
         # epoll reactor threads of the native gRPC front (each owns the connections it accepted)
-        # four epoll threads: neutral for requests that carry region references, +20 % for requests that carry
-        # their tensors (1.2 MB each at batch 8: 36-39k -> 43-44k img/s; receiving is the reactors' work)
-        self._grpc_reactors = int(grpc_reactors or os.environ.get("TCA_GRPC_REACTORS") or 4)
+        # eight epoll threads: neutral for requests that carry region references; for requests that carry their
+        # tensors (1.2 MB each at batch 8) receiving and staging is the reactors' work, and with four of them
+        # the rate fell once more than ~32 requests were in flight (47k img/s at 32, 36k at 64, small batches on
+        # the GPU); with eight it keeps rising: 49k / 54k / 58k img/s at 32 / 64 / 128
+        self._grpc_reactors = int(grpc_reactors or os.environ.get("TCA_GRPC_REACTORS") or 8)
         # requests for models with a C++ kernel are answered by the native fronts without the
         # interpreter (tca/native_executor.h); TCA_NATIVE_EXEC=0 / native_exec=False turns that off
         if native_exec is None:
