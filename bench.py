@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--connections", type=int, default=8, help="gRPC channels the native load generator spreads over")
     ap.add_argument("--image-requests", type=int, default=16384,
                     help="requests of the end-to-end image pipeline run (extra.image_client)")
+    ap.add_argument("--ensemble-requests", type=int, default=3072,
+                    help="requests (8 PNG files each) of the server-side preprocessing run (extra.ensemble)")
     ap.add_argument("--image-lanes", type=int, default=3)
     ap.add_argument("--image-depth", type=int, default=6)
     ap.add_argument("--sweep", default="1,4,16,64,256",
@@ -572,6 +574,111 @@ def measure_image_client(args, url, device):
         pipe.close()
 
 
+def measure_ensemble(args, server, device):
+    """``preprocess_resnet50_ensemble``: PNG files (224x224, eight per request) inside gRPC requests, top-3
+    classes out, 32 requests in flight.  The server decodes on a thread pool, preprocesses with the HIP
+    kernel and runs the classifier as a step through resnet50's dynamic batcher.  The first answer is
+    compared with the same images through client-side preprocessing + ``resnet50``."""
+    import io
+    import threading
+
+    import numpy as np
+    import tritonclient.grpc as grpcclient
+    from PIL import Image
+
+    from triton_client_amd.ops.preprocess import Preprocessor
+
+    b, inflight, total = 8, 32, args.ensemble_requests
+    sets = []
+    raw_first = None
+    for k in range(8):
+        imgs = structured_images(b, first=9000 + 1000 * device + k * b, height=224, width=224)
+        if raw_first is None:
+            raw_first = imgs
+        blobs = []
+        for img in imgs:
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, "PNG", compress_level=3)
+            blobs.append(buf.getvalue())
+        inp = grpcclient.InferInput("INPUT", [b, 1], "BYTES")
+        inp.set_data_from_numpy(np.array(blobs, dtype=np.object_).reshape(b, 1))
+        sets.append([inp])
+    outputs = [grpcclient.InferRequestedOutput("OUTPUT", class_count=3)]
+    control = grpcclient.InferenceServerClient(server.grpc_url)
+    clients = [grpcclient.InferenceServerClient(server.grpc_url) for _ in range(4)]
+    try:
+        lock = threading.Lock()
+        done = threading.Event()
+        state = {"issued": 0, "finished": 0, "errors": 0, "first": None, "lat": [], "goal": 0}
+
+        def issue(slot):
+            with lock:
+                if state["issued"] >= state["goal"]:
+                    return
+                n = state["issued"]
+                state["issued"] += 1
+            t0 = time.perf_counter()
+
+            def on_done(result, error, t0=t0, slot=slot, n=n):
+                with lock:
+                    state["finished"] += 1
+                    if error is not None:
+                        state["errors"] += 1
+                        state["first_error"] = str(error)
+                    else:
+                        state["lat"].append(time.perf_counter() - t0)
+                        if n == 0:
+                            state["first"] = result
+                    last = state["finished"] >= state["goal"]
+                if last:
+                    done.set()
+                else:
+                    issue(slot)
+
+            clients[slot % len(clients)].async_infer("preprocess_resnet50_ensemble", sets[n % len(sets)], on_done,
+                                                     outputs=outputs)
+
+        def run(goal):
+            with lock:
+                state.update(issued=0, finished=0, errors=0, lat=[], goal=goal)
+            done.clear()
+            t0 = time.perf_counter()
+            for slot in range(min(inflight, goal)):
+                issue(slot)
+            if not done.wait(timeout=args.generator_timeout):
+                raise RuntimeError("ensemble run did not finish")
+            return time.perf_counter() - t0
+
+        run(max(64, total // 8))
+        elapsed = run(total)
+        if state["errors"]:
+            raise RuntimeError(f"{state['errors']} ensemble requests failed: {state.get('first_error')}")
+        lat = sorted(state["lat"])
+        top = [e.decode() for e in state["first"].as_numpy("OUTPUT").reshape(b, 3)[0]]
+        # the same eight images through client-side preprocessing and the classifier itself
+        import torch
+
+        pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=device, max_batch=8)
+        x = torch.empty(b, 3, 224, 224, device=f"cuda:{device}", dtype=torch.float16)
+        pre(raw_first, x)
+        pre.close()
+        inp = grpcclient.InferInput("input", [b, 3, 224, 224], "FP16")
+        inp.set_data_from_numpy(x.cpu().numpy())
+        ref = control.infer(args.model, [inp], outputs=[grpcclient.InferRequestedOutput("output", class_count=3)])
+        ref_top = [e.decode() for e in ref.as_numpy("output").reshape(b, 3)[0]]
+        same = [t.split(":")[1] for t in top] == [t.split(":")[1] for t in ref_top]
+        return {"images_per_sec": round(total * b / elapsed, 1), "requests": total, "batch": b, "concurrency": inflight,
+                "elapsed_s": round(elapsed, 4), "p50_latency_us": round(lat[len(lat) // 2] * 1e6, 1),
+                "p99_latency_us": round(lat[int(len(lat) * 0.99)] * 1e6, 1),
+                "source": "224x224 PNG files inside the requests (BYTES), decoded by the server",
+                "client": "Python (tritonclient.grpc async_infer, 4 channels)", "first_result_top3": top,
+                "top3_equals_client_side_preprocessing": bool(same)}
+    finally:
+        control.close()
+        for c in clients:
+            c.close()
+
+
 def measure_secondary(args, device, dist):
     """The other configurations of the benchmark set, each on this rank's own server and GPU:
     `simple` over HTTP + system shared memory, `simple` over gRPC with tensors on the wire,
@@ -847,7 +954,9 @@ def main():
 
     from triton_client_amd.server import spawn_server
 
-    server = spawn_server(models=[args.model], gpu=device,
+    with_ensemble = (not args.no_extras and args.client == "native" and args.protocol == "grpc" and args.mode == "serve"
+                     and world == 1 and args.model == "resnet50")
+    server = spawn_server(models=[args.model] + (["preprocess_resnet50_ensemble"] if with_ensemble else []), gpu=device,
                           extra_args=["--grpc-workers", str(max(32, 2 * args.concurrency)), "--http-workers",
                                       str(max(16, 2 * args.concurrency))])
     try:
@@ -879,6 +988,11 @@ def main():
                     extras["image_client"] = measure_image_client(args, url, device)
                 except BaseException as e:  # noqa: BLE001 - the headline number must survive
                     extras["image_client"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            if with_ensemble:
+                try:
+                    extras["ensemble"] = measure_ensemble(args, server, device)
+                except BaseException as e:  # noqa: BLE001 - the headline number must survive
+                    extras["ensemble"] = {"error": f"{type(e).__name__}: {e}"[:500]}
     finally:
         server.stop()
     if dist is not None:

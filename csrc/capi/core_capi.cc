@@ -5,6 +5,8 @@
 // and reads/writes are bounds checked here rather than in Python.
 #include <cerrno>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -15,8 +17,13 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
 #include "tca/base64.h"
 #include "tca/codec.h"
+#include "tca/image_io.h"
 #include "tca/shm_utils.h"
 
 namespace {
@@ -182,6 +189,63 @@ int64_t tca_base64_decode(const char* src, uint64_t n, void* dst, uint64_t cap) 
   if (!tca::Base64Decode(src, n, &out)) return kErrFormat;
   if (dst && out.size() <= cap) std::memcpy(dst, out.data(), out.size());
   return static_cast<int64_t>(out.size());
+}
+
+// ---- image files -> pixels ------------------------------------------------------------------
+// A batch of encoded image files (PNG, sequential JPEG, binary PNM - by signature) decoded side by side on
+// native threads: the caller (a Python model behind a serving front) holds no interpreter lock while this
+// runs.  `channels`: 0 keeps what the file has, 1 / 3 converts.  Every entry of `out` is filled: pixels
+// (malloc'ed, HWC, rows top to bottom; freed by tca_free_images) and geometry, or a message in `error`.
+struct TcaImage {
+  int32_t height, width, channels;
+  uint8_t* pixels;
+  char error[128];
+};
+
+int tca_decode_images(int n, const void* const* data, const uint64_t* sizes, int channels, int threads, TcaImage* out) {
+  if (n < 0 || (n > 0 && (!data || !sizes || !out)) || (channels != 0 && channels != 1 && channels != 3)) return kErrBadArg;
+  for (int i = 0; i < n; ++i) {
+    out[i].height = out[i].width = out[i].channels = 0;
+    out[i].pixels = nullptr;
+    out[i].error[0] = 0;
+  }
+  std::atomic<int> next{0}, failed{0};
+  auto work = [&] {
+    for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+      tca::DecodedImage img, converted;
+      tca::Error e = tca::DecodeImage(static_cast<const uint8_t*>(data[i]), static_cast<size_t>(sizes[i]), &img);
+      if (e.IsOk() && channels != 0 && img.channels != channels) {
+        tca::ConvertChannels(img, channels, &converted);
+        img = std::move(converted);
+      }
+      if (e.IsOk()) {
+        out[i].pixels = static_cast<uint8_t*>(std::malloc(img.pixels.size() ? img.pixels.size() : 1));
+        if (out[i].pixels == nullptr) e = tca::Error("out of memory");
+      }
+      if (!e.IsOk()) {
+        std::snprintf(out[i].error, sizeof(out[i].error), "%s", e.Message().c_str());
+        ++failed;
+        continue;
+      }
+      std::memcpy(out[i].pixels, img.pixels.data(), img.pixels.size());
+      out[i].height = img.height;
+      out[i].width = img.width;
+      out[i].channels = img.channels;
+    }
+  };
+  const int workers = std::max(1, std::min(threads, n));
+  std::vector<std::thread> pool;
+  for (int t = 1; t < workers; ++t) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  return failed.load();
+}
+
+void tca_free_images(int n, TcaImage* images) {
+  for (int i = 0; i < n; ++i) {
+    std::free(images[i].pixels);
+    images[i].pixels = nullptr;
+  }
 }
 
 }  // extern "C"

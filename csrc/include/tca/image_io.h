@@ -35,6 +35,9 @@ Error DecodeJpeg(const uint8_t* data, size_t size, DecodedImage* out);
 // Binary PGM (P5) / PPM (P6) with maxval 255.
 Error DecodePnm(const uint8_t* data, size_t size, DecodedImage* out);
 
+// Decodes an image file held in memory by its signature (PNG, JPEG, binary PNM).
+Error DecodeImage(const uint8_t* data, size_t size, DecodedImage* out);
+
 // Reads a file and decodes it by its signature.
 Error ReadImageFile(const std::string& path, DecodedImage* out);
 

@@ -341,3 +341,42 @@ def test_cpp_image_client_png_files(built, server, tmp_path, protocol, mode):
                 "-s", "INCEPTION", *files])
     pick = lambda text: [line for line in text.splitlines() if line.startswith("    ")]  # noqa: E731
     assert pick(out) == pick(ref)
+
+
+def test_batch_image_decode_c_api(tmp_path):
+    """``tca_decode_images`` behind ``ops.image_decode.decode_images``: a mixed batch (PNG of several colour
+    types, JPEG, PNM) decoded on native threads equals Pillow; what the native readers refuse (progressive
+    JPEG) falls back to Pillow; garbage is reported with the index of the file."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    from triton_client_amd.ops.image_decode import decode_images
+
+    rgb = _jpeg_photo(61, 83)
+    blobs, want = [], []
+    for fmt, kw in (("PNG", {}), ("JPEG", {"quality": 90}), ("JPEG", {"quality": 70, "subsampling": 0}), ("PPM", {}),
+                    ("JPEG", {"quality": 85, "progressive": True})):
+        buf = io.BytesIO()
+        Image.fromarray(rgb).save(buf, fmt, **kw)
+        blobs.append(buf.getvalue())
+        want.append(np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB")))
+    buf = io.BytesIO()
+    Image.fromarray(rgb).convert("RGBA").save(buf, "PNG")
+    blobs.append(buf.getvalue())
+    want.append(rgb)
+    buf = io.BytesIO()
+    Image.fromarray(rgb[..., 0]).save(buf, "PNG")
+    blobs.append(buf.getvalue())
+    want.append(np.repeat(rgb[..., :1], 3, axis=2))
+    for threads in (1, 4):
+        got = decode_images(blobs, channels=3, threads=threads)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g.dtype == np.uint8 and g.shape == w.shape and np.abs(g.astype(int) - w.astype(int)).max() <= 1
+    gray = decode_images(blobs[:1], channels=1)[0]
+    assert gray.shape == (61, 83) and np.abs(gray.astype(int) - np.asarray(Image.fromarray(rgb).convert("L")).astype(int)).max() <= 1
+    with pytest.raises(ValueError, match="image 1"):
+        decode_images([blobs[0], b"not an image"], channels=3)
+    assert decode_images([], channels=3) == []

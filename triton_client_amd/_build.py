@@ -8,7 +8,7 @@ on a CPU-only build host.
 
 Targets
 -------
-core   : libtca_core.so      (g++   – system shm, codec, base64 C ABI)
+core   : libtca_core.so      (g++   – system shm, codec, base64, image decoding C ABI)
 pyext  : _tca_pyext*.so      (g++   – CPython BYTES pack/unpack, native gRPC serving front)
 hip    : libtca_hip.so       (hipcc – hipshm + CDNA4 kernels)
 cpp    : build/libtcaclient.{a,so}, C++ examples, tests and the perf driver
@@ -61,10 +61,11 @@ def _compile_atomic(cmd, out: Path):
 def build_core(force=False):
     out = LIBDIR / "libtca_core.so"
     srcs = [CSRC / "core" / "base64.cc", CSRC / "core" / "codec.cc", CSRC / "core" / "shm_utils.cc",
+            CSRC / "core" / "common.cc", CSRC / "core" / "image_io.cc", CSRC / "core" / "jpeg.cc",
             CSRC / "capi" / "core_capi.cc"]
     if force or _stale(out, srcs):
         LIBDIR.mkdir(exist_ok=True)
-        _compile_atomic(["g++", *CXXFLAGS, "-shared", "-o", out, *srcs, "-lrt", "-pthread"], out)
+        _compile_atomic(["g++", *CXXFLAGS, "-shared", "-o", out, *srcs, "-lrt", "-lz", "-pthread"], out)
     return out
 
 

@@ -65,6 +65,10 @@ def core():
         lib.tca_base64_encode.argtypes = [c_void_p, c_uint64, c_char_p, c_uint64]
         lib.tca_base64_decode.restype = c_int64
         lib.tca_base64_decode.argtypes = [c_char_p, c_uint64, c_void_p, c_uint64]
+        lib.tca_decode_images.restype = c_int
+        lib.tca_decode_images.argtypes = [c_int, POINTER(c_void_p), POINTER(c_uint64), c_int, c_int, c_void_p]
+        lib.tca_free_images.restype = None
+        lib.tca_free_images.argtypes = [c_int, c_void_p]
         _core = lib
     return _core
 

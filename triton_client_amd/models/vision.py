@@ -696,16 +696,19 @@ class ResNet50Fp32In(ResNet50):
 class PreprocessResNet50Ensemble(Model):
     """Encoded image files in, ImageNet logits out, everything after the decode on
     the GPU: JPEG / PNG bytes (a BYTES tensor, one file per batch entry) are decoded
-    on the host, resized + INCEPTION-scaled + laid out as fp16 NCHW by the HIP
-    preprocessing kernel (bit-exact with the Pillow pipeline of ``image_client``)
-    straight into the classifier's input buffer, and classified by the loaded
-    ``resnet50`` instance.  This is the GPU counterpart of the reference's
+    on the host (the C++ library's decoders, a request's files side by side on native threads),
+    resized + INCEPTION-scaled + laid out as fp16 NCHW by the HIP preprocessing
+    kernel (bit-exact with the Pillow pipeline of ``image_client``), and classified
+    as a step through the loaded ``resnet50``'s dynamic batcher: concurrent ensemble
+    requests are merged into one classifier batch like any other requests for that
+    model.  This is the GPU counterpart of the reference's
     ``preprocess_inception_ensemble`` (server-side DALI preprocessing,
     ``src/python/examples/ensemble_image_client.py:60-110``)."""
 
     name = "preprocess_resnet50_ensemble"
     platform = "ensemble"
     device = "gpu"
+    concurrent = True  # requests run side by side (decode pool, two preprocessors, the step's batcher merges them)
     max_batch_size = 64
     inputs = [TensorSpec("INPUT", "BYTES", [1])]
     outputs = [TensorSpec("OUTPUT", "FP32", [1000], label_filename="labels.txt")]
@@ -726,12 +729,20 @@ class PreprocessResNet50Ensemble(Model):
         self._torch = torch
         index = device_index or 0
         self._device = torch.device("cuda", index)
-        self._pre = Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=index,
-                                 max_batch=self.max_batch_size)
+        # two preprocessors (staging buffers + stream each): one request stages its images while the kernel
+        # of another runs
+        self._pres = [Preprocessor(224, 224, 3, "NCHW", "FP16", scaling="INCEPTION", device=index,
+                                   max_batch=self.max_batch_size) for _ in range(2)]
+        self._pre = self._pres[0]
+        self._pre_locks = [threading.Lock() for _ in self._pres]
+        self._turn = 0
+        self._decode_threads = int(os.environ.get("TCA_ENSEMBLE_DECODERS", "4"))  # per request, at most
+        self._active = 0
 
     def unload(self):
         if self._pre is not None:
-            self._pre.close()
+            for pre in self._pres:
+                pre.close()
             self._pre = None
 
     def _classifier(self):
@@ -745,25 +756,36 @@ class PreprocessResNet50Ensemble(Model):
         return self._classifier().stream
 
     def execute(self, inputs, ctx):
-        import io
-
-        import numpy as np
-        from PIL import Image
+        from ..ops.image_decode import decode_images
 
         torch = self._torch
         net = self._classifier()
-        images = []
-        for blob in inputs["INPUT"].reshape(-1):
-            try:
-                img = Image.open(io.BytesIO(blob))
-                img.load()
-            except Exception as e:
-                raise ModelError(f"unable to decode image: {e}") from None
-            images.append(np.asarray(img.convert("RGB")))
-        with self._lock:  # one staging buffer set per preprocessor
-            x = torch.empty(len(images), 3, 224, 224, device=self._device, dtype=torch.float16)
-            self._pre(images, x)  # synchronises its own stream: x is complete on return
-            return {"OUTPUT": net.run(x)}
+
+        blobs = list(inputs["INPUT"].reshape(-1))
+        with self._lock:
+            self._active += 1
+            # a lone request spreads its files over a few threads; many requests at once are parallel already
+            threads = max(1, min(self._decode_threads, 8 // self._active))
+        try:
+            # one native call for the batch, no interpreter lock held meanwhile
+            images = decode_images(blobs, channels=3, threads=threads)
+        except ValueError as e:
+            raise ModelError(f"unable to decode image: {e}") from None
+        finally:
+            with self._lock:
+                self._active -= 1
+        with self._lock:
+            self._turn = which = (self._turn + 1) % len(self._pres)
+        x = torch.empty(len(images), 3, 224, 224, device=self._device, dtype=torch.float16)
+        with self._pre_locks[which]:  # one staging buffer set per preprocessor
+            self._pres[which](images, x)  # synchronises its own stream: x is complete on return
+        core = getattr(self, "core", None)
+        if core is not None and getattr(net, "core", None) is core:
+            return {"OUTPUT": core.infer_tensors("resnet50", {"input": x}, len(images))["output"]}
+        with self._lock:  # stand-alone use (no serving core around the two models)
+            out = net.run(x)
+            net.stream.synchronize()
+            return {"OUTPUT": out.float().cpu().numpy()}
 
     def config(self):
         cfg = super().config()

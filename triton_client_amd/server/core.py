@@ -23,6 +23,7 @@ and back from :class:`InferResponse`.
 from __future__ import annotations
 
 import base64
+import contextlib
 import copy
 import json
 import math
@@ -870,6 +871,7 @@ class InferenceCore:
             model.capture_gate = self.native
         if hasattr(model, "evict_region"):
             self.devshm.on_close.append(model.evict_region)
+        model.core = self  # ensembles run their steps through infer_tensors()
         if model.device == "gpu" and model.dynamic_batching:
             from .batcher import DynamicBatcher
 
@@ -1509,6 +1511,26 @@ class InferenceCore:
         return response
 
     # -- GPU helpers (torch imported lazily: CPU-only servers never need it) --
+    def infer_tensors(self, model_name, inputs, batch):
+        """A step of an ensemble: run ``inputs`` (name -> device tensor or array with a leading batch axis)
+        through a loaded model the way a request goes - behind the dynamic batcher it is merged with
+        whatever else is queued for that model, whoever sent it - and return ``{output name: array}``.
+        Blocks the calling (worker) thread; counted in the step model's statistics."""
+        lm = self._get(model_name, "")
+        model = lm.model
+        version = model.versions[-1]
+        requested = [RequestedOutput(name=t.name) for t in model.outputs]
+        ctx = ExecContext(request_id="", parameters={}, version=version, requested_outputs=[r.name for r in requested])
+        ctx.stable_inputs = set()
+        req = InferRequest(model_name)
+        t_arrive = time.perf_counter_ns()
+        if lm.batcher is not None:
+            resp = lm.batcher.submit(req, inputs, int(batch), set(), requested, ctx, lm.stats[version], t_arrive, version)
+        else:
+            resp = self._run_gpu_single(lm, req, inputs, int(batch), set(), requested, ctx, lm.stats[version], t_arrive,
+                                        version)
+        return {o.name: o.data for o in resp.outputs}
+
     def _to_device(self, lm, inputs, stable):
         import torch
 
@@ -1529,7 +1551,9 @@ class InferenceCore:
         model = lm.model
         out_specs = {t.name: t for t in model.outputs}
         t0 = time.perf_counter_ns()
-        with lm.exec_lock:
+        # models that keep their own locks (an ensemble: its requests wait side by side for the step models'
+        # batchers) run their requests concurrently
+        with (contextlib.nullcontext() if getattr(model, "concurrent", False) else lm.exec_lock):
             t_exec = time.perf_counter_ns()
             dev_inputs = self._to_device(lm, inputs, stable)
             for ro in requested:
@@ -1538,7 +1562,8 @@ class InferenceCore:
                     dev_inputs["__out__" + ro.name] = dest
             t1 = time.perf_counter_ns()
             result = model.execute(dev_inputs, ctx)
-            model.stream.synchronize()
+            if not getattr(model, "concurrent", False):
+                model.stream.synchronize()
             t2 = time.perf_counter_ns()
         response = self._build_response(lm, req, result, requested, out_specs, version, batch, dev_inputs)
         t3 = time.perf_counter_ns()
