@@ -210,7 +210,10 @@ class DynamicBatcher:
                 pinned = self._pins.get(hint)
                 if pinned is None:
                     if len(self._pins) >= 4096:
-                        self._pins.clear()
+                        # drop the oldest half (insertion order), not everything: the regions in use keep
+                        # their instance, and with it the graphs already captured for their addresses
+                        for key in list(self._pins)[:2048]:
+                            del self._pins[key]
                     pinned = self._pins[hint] = inst
                 if self._busy[pinned] <= self._busy[inst]:
                     inst = pinned
