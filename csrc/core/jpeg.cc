@@ -1,6 +1,7 @@
-// JPEG decoder for the image examples: Huffman-coded sequential DCT, 8-bit (SOF0 baseline and SOF1 extended),
+// JPEG decoder for the image examples: Huffman-coded DCT, 8-bit - sequential (SOF0 baseline, SOF1 extended) and
+// progressive (SOF2: spectral selection and successive approximation, coefficients kept until the last scan) -
 // gray or three components, any mix of 1x / 2x sampling factors, interleaved or one scan per component,
-// restart intervals, 8- and 16-bit quantisation tables.  Progressive, arithmetic-coded, lossless, 12-bit and
+// restart intervals, 8- and 16-bit quantisation tables.  Arithmetic-coded, lossless, 12-bit and
 // four-component (CMYK) files are reported as unsupported.
 //
 // The reference's image clients read files with OpenCV's imread (`src/c++/examples/image_client.cc:85-105`),
@@ -131,6 +132,7 @@ struct Component {
   int pred = 0;
   bool scanned = false;
   std::vector<uint8_t> plane;
+  std::vector<int16_t> coefs;  // progressive files: every block's 64 coefficients (natural order) until the last scan
 };
 
 // libjpeg's jpeg_idct_islow: dequantised coefficients -> 8x8 samples (level shift and clamp included).
@@ -253,7 +255,9 @@ struct Decoder {
   size_t pos = 2;
   int width = 0, height = 0, hmax = 1, vmax = 1;
   int restart_interval = 0;
-  bool have_frame = false, adobe = false;
+  bool have_frame = false, adobe = false, progressive = false;
+  int ss = 0, se = 63, ah = 0, al = 0;  // spectral selection / successive approximation of the current scan
+  int eobrun = 0;                       // progressive AC scans: blocks left whose band is all zero
   int adobe_transform = -1;
   std::vector<Component> comps;
   uint16_t quant[4][64];  // natural order
@@ -289,8 +293,9 @@ struct Decoder {
     return Error::Success();
   }
 
-  Error Sof(const uint8_t* p, size_t n) {
+  Error Sof(const uint8_t* p, size_t n, bool is_progressive) {
     if (have_frame) return Error("JPEG: more than one frame");
+    progressive = is_progressive;
     if (n < 6) return Error("JPEG: bad frame header");
     if (p[0] != 8) return Error("JPEG: only 8-bit samples are supported");
     height = (p[1] << 8) | p[2];
@@ -320,6 +325,7 @@ struct Decoder {
       c.pw = mcux * c.h * 8;
       c.ph = mcuy * c.v * 8;
       c.plane.assign(static_cast<size_t>(c.pw) * c.ph, 128);
+      if (progressive) c.coefs.assign(static_cast<size_t>(c.pw) * c.ph, 0);
     }
     have_frame = true;
     return Error::Success();
@@ -352,6 +358,86 @@ struct Decoder {
     return Error::Success();
   }
 
+  // Progressive scans (libjpeg jdphuff.c): each adds bits to the stored coefficients of one band.
+  Error ProgressiveBlock(BitReader* br, Component* c, int bx, int by) {
+    int16_t* block = &c->coefs[(static_cast<size_t>(by) * (c->pw / 8) + bx) * 64];
+    if (ss == 0) {
+      if (ah == 0) {  // first DC scan: the difference, scaled by the point transform
+        const int s = DecodeSymbol(br, dc[c->td]);
+        if (s < 0 || s > 11) return Error("JPEG: bad DC code");
+        c->pred += s ? Extend(br->Receive(s), s) : 0;
+        block[0] = static_cast<int16_t>(c->pred * (1 << al));
+      } else if (br->Receive(1)) {  // DC refinement: one more bit
+        block[0] = static_cast<int16_t>(block[0] | (1 << al));
+      }
+      return Error::Success();
+    }
+    const HuffTable& a = ac[c->ta];
+    if (ah == 0) {  // first AC scan of the band
+      if (eobrun > 0) {
+        --eobrun;
+        return Error::Success();
+      }
+      for (int k = ss; k <= se; ++k) {
+        const int rs = DecodeSymbol(br, a);
+        if (rs < 0) return Error("JPEG: bad AC code");
+        const int r = rs >> 4, sz = rs & 15;
+        if (sz) {
+          k += r;
+          if (k > se) return Error("JPEG: coefficient index out of range");
+          block[kZigzag[k]] = static_cast<int16_t>(Extend(br->Receive(sz), sz) * (1 << al));
+        } else if (r == 15) {
+          k += 15;
+        } else {  // end of band for this block and eobrun - 1 more
+          eobrun = (1 << r) + (r ? br->Receive(r) : 0) - 1;
+          break;
+        }
+      }
+      return Error::Success();
+    }
+    // AC refinement: correction bits for the coefficients that are nonzero already, new ones of magnitude 1 << al
+    const int p1 = 1 << al, m1 = -(1 << al);
+    auto correct = [&](int16_t* coef) {
+      if (br->Receive(1) && (*coef & p1) == 0) *coef = static_cast<int16_t>(*coef >= 0 ? *coef + p1 : *coef + m1);
+    };
+    int k = ss;
+    if (eobrun == 0) {
+      for (; k <= se; ++k) {
+        const int rs = DecodeSymbol(br, a);
+        if (rs < 0) return Error("JPEG: bad AC code");
+        int r = rs >> 4, value = 0;
+        if (rs & 15) {
+          if ((rs & 15) != 1) return Error("JPEG: bad refinement code");
+          value = br->Receive(1) ? p1 : m1;
+        } else if (r != 15) {
+          eobrun = (1 << r) + (r ? br->Receive(r) : 0);
+          break;  // the rest of the band below
+        }
+        do {  // over nonzero coefficients (a correction bit each) and r zero ones
+          int16_t* coef = block + kZigzag[k];
+          if (*coef != 0) {
+            correct(coef);
+          } else if (--r < 0) {
+            break;
+          }
+          ++k;
+        } while (k <= se);
+        if (value) {
+          if (k > se) return Error("JPEG: coefficient index out of range");
+          block[kZigzag[k]] = static_cast<int16_t>(value);
+        }
+      }
+    }
+    if (eobrun > 0) {
+      for (; k <= se; ++k) {
+        int16_t* coef = block + kZigzag[k];
+        if (*coef != 0) correct(coef);
+      }
+      --eobrun;
+    }
+    return Error::Success();
+  }
+
   // After the scan header at `pos`: entropy-coded data up to the next marker that is not a restart marker.
   Error Scan(const uint8_t* p, size_t n) {
     if (!have_frame) return Error("JPEG: scan before the frame header");
@@ -366,15 +452,28 @@ struct Decoder {
       if (found == nullptr) return Error("JPEG: scan names an unknown component");
       found->td = p[2 + 2 * i] >> 4;
       found->ta = p[2 + 2 * i] & 15;
-      if (found->td > 3 || found->ta > 3 || !dc[found->td].present || !ac[found->ta].present)
-        return Error("JPEG: scan uses a Huffman table that was not defined");
+      if (found->td > 3 || found->ta > 3) return Error("JPEG: bad table selector in a scan header");
       if (!have_quant[found->tq]) return Error("JPEG: component uses a quantisation table that was not defined");
       found->pred = 0;
       found->scanned = true;
       in_scan.push_back(found);
     }
-    if (p[1 + 2 * ns] != 0 || p[2 + 2 * ns] != 63 || p[3 + 2 * ns] != 0)
-      return Error("JPEG: spectral selection / successive approximation belong to progressive files");
+    ss = p[1 + 2 * ns];
+    se = p[2 + 2 * ns];
+    ah = p[3 + 2 * ns] >> 4;
+    al = p[3 + 2 * ns] & 15;
+    if (!progressive) {
+      if (ss != 0 || se != 63 || ah != 0 || al != 0)
+        return Error("JPEG: spectral selection / successive approximation belong to progressive files");
+    } else if (ss > se || se > 63 || al > 13 || ah > 13 || (ss == 0 && se != 0) || (ss != 0 && ns != 1)) {
+      return Error("JPEG: bad progressive scan parameters");
+    }
+    for (const Component* c : in_scan) {  // the tables this kind of scan reads
+      const bool need_dc = !progressive || (ss == 0 && ah == 0), need_ac = !progressive || ss != 0;
+      if ((need_dc && !dc[c->td].present) || (need_ac && !ac[c->ta].present))
+        return Error("JPEG: scan uses a Huffman table that was not defined");
+    }
+    eobrun = 0;
     BitReader br;
     br.p = data + pos;
     br.end = data + size;
@@ -402,17 +501,19 @@ struct Decoder {
         next_rst = (next_rst + 1) & 7;
         br.p = q + 2;
         for (Component* c : in_scan) c->pred = 0;
+        eobrun = 0;
         until_restart = restart_interval;
       }
       const int mx = static_cast<int>(m % mcus_x), my = static_cast<int>(m / mcus_x);
       if (ns == 1) {
-        const Error e = DecodeBlock(&br, in_scan[0], mx, my);
+        const Error e = progressive ? ProgressiveBlock(&br, in_scan[0], mx, my) : DecodeBlock(&br, in_scan[0], mx, my);
         if (!e.IsOk()) return e;
       } else {
         for (Component* c : in_scan)
           for (int vy = 0; vy < c->v; ++vy)
             for (int hx = 0; hx < c->h; ++hx) {
-              const Error e = DecodeBlock(&br, c, mx * c->h + hx, my * c->v + vy);
+              const int bx = mx * c->h + hx, by = my * c->v + vy;
+              const Error e = progressive ? ProgressiveBlock(&br, c, bx, by) : DecodeBlock(&br, c, bx, by);
               if (!e.IsOk()) return e;
             }
       }
@@ -502,6 +603,16 @@ struct Decoder {
   Error Finish(DecodedImage* out) {
     for (const auto& c : comps)
       if (!c.scanned) return Error("JPEG: a component has no scan");
+    if (progressive) {  // every scan is in: coefficients -> samples
+      for (auto& c : comps) {
+        const int bw = c.pw / 8, bh = c.ph / 8;
+        for (int by = 0; by < bh; ++by)
+          for (int bx = 0; bx < bw; ++bx)
+            IdctIslow(&c.coefs[(static_cast<size_t>(by) * bw + bx) * 64], quant[c.tq],
+                      &c.plane[static_cast<size_t>(by) * 8 * c.pw + static_cast<size_t>(bx) * 8], c.pw);
+        std::vector<int16_t>().swap(c.coefs);
+      }
+    }
     out->width = width;
     out->height = height;
     out->channels = static_cast<int>(comps.size());
@@ -579,10 +690,11 @@ struct Decoder {
       switch (marker) {
         case 0xC0:
         case 0xC1:
-          e = Sof(p, n);
+          e = Sof(p, n, false);
           break;
         case 0xC2:
-          return Error("JPEG: progressive files are not supported (sequential Huffman-coded files are)");
+          e = Sof(p, n, true);
+          break;
         case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
           return Error("JPEG: lossless, hierarchical and arithmetic-coded files are not supported");
         case 0xC4:

@@ -1,4 +1,4 @@
-// Image file readers for the examples and tools: PNG (on zlib), JPEG (sequential, Huffman-coded) and
+// Image file readers for the examples and tools: PNG (on zlib), JPEG (Huffman-coded, sequential and progressive) and
 // binary PNM.  The reference's C++ image clients lean on OpenCV's imread
 // (`src/c++/examples/image_client.cc:85-105`); these cover the formats image classifiers are fed with
 // and need nothing beyond zlib.
@@ -26,10 +26,10 @@ struct DecodedImage {
 // zlib checksum are verified.
 Error DecodePng(const uint8_t* data, size_t size, DecodedImage* out);
 
-// JPEG: baseline and extended sequential DCT (SOF0 / SOF1), 8-bit, gray or YCbCr / RGB with any mix of
-// 1x and 2x sampling factors, restart intervals, one or several scans.  Pixels equal libjpeg's default
-// decode (slow integer IDCT, triangle-filter chroma upsampling).  Progressive, arithmetic-coded, 12-bit
-// and CMYK files are refused with a message that says so.
+// JPEG: sequential (SOF0 / SOF1) and progressive (SOF2) Huffman-coded DCT, 8-bit, gray or YCbCr / RGB with any
+// mix of 1x and 2x sampling factors, restart intervals, one or several scans.  Pixels equal libjpeg's default
+// decode (slow integer IDCT, triangle-filter chroma upsampling).  Arithmetic-coded, 12-bit and CMYK files
+// are refused with a message that says so.
 Error DecodeJpeg(const uint8_t* data, size_t size, DecodedImage* out);
 
 // Binary PGM (P5) / PPM (P6) with maxval 255.

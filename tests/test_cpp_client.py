@@ -235,10 +235,10 @@ def _jpeg_photo(h, w, seed=5):
 def test_cpp_jpeg_reader_matches_pillow(built, tmp_path):
     """The JPEG decoder of the C++ library against Pillow (libjpeg-turbo, default settings) over chroma
     subsampling modes, qualities, image sizes that are not multiples of the block size (down to 1x1), gray
-    files, optimised Huffman tables and restart intervals.  The decoder follows libjpeg's arithmetic, so the
-    pixels are expected to be equal; the assertion allows a difference of 1 for Pillow builds on another
-    libjpeg.  Progressive files are refused by name.  4:4:0 files (vertical-only subsampling) are not covered:
-    Pillow cannot write them - parity unpinned."""
+    files, optimised Huffman tables, restart intervals and progressive files.  The decoder follows libjpeg's
+    arithmetic, so the pixels are expected to be equal; the assertion allows a difference of 1 for Pillow
+    builds on another libjpeg.  CMYK files are refused by name.  4:4:0 files (vertical-only subsampling) are
+    not covered: Pillow cannot write them - parity unpinned."""
     import numpy as np
     from PIL import Image
 
@@ -259,6 +259,19 @@ def test_cpp_jpeg_reader_matches_pillow(built, tmp_path):
         path = str(tmp_path / f"{name}.jpg")
         im.save(path, **{"quality": 85, **kw})
         expected[path] = None
+    # progressive files (spectral selection + successive approximation), with restart intervals too
+    for (h, w) in [(37, 53), (1, 1), (8, 17), (121, 159)]:
+        pim = Image.fromarray(_jpeg_photo(h, w, seed=9))
+        for ss in (0, 1, 2):
+            path = str(tmp_path / f"p_{h}x{w}_s{ss}.jpg")
+            pim.save(path, quality=80, subsampling=ss, progressive=True)
+            expected[path] = None
+        path = str(tmp_path / f"pg_{h}x{w}.jpg")
+        pim.convert("L").save(path, quality=80, progressive=True)
+        expected[path] = None
+    path = str(tmp_path / "prst.jpg")
+    im.save(path, quality=85, progressive=True, subsampling=2, restart_marker_blocks=3)
+    expected[path] = None
     for path in expected:
         expected[path] = np.asarray(Image.open(path))
     dump = tmp_path / "dump"
@@ -279,16 +292,17 @@ def test_cpp_jpeg_reader_matches_pillow(built, tmp_path):
 
     if features.check_feature("libjpeg_turbo"):
         assert exact == len(expected)
-    prog = str(tmp_path / "prog.jpg")
-    im.save(prog, quality=85, progressive=True)
-    p = subprocess.run([os.path.join(built, "image_client"), "--decode-only", prog], capture_output=True, text=True)
-    assert p.returncode != 0 and "progressive" in (p.stdout + p.stderr)
+    # a format nobody here reads is refused by name
+    cmyk = str(tmp_path / "cmyk.jpg")
+    im.convert("CMYK").save(cmyk, quality=85)
+    p = subprocess.run([os.path.join(built, "image_client"), "--decode-only", cmyk], capture_output=True, text=True)
+    assert p.returncode != 0 and "4-component" in (p.stdout + p.stderr)
     # damaged files end with a message, not a crash: truncated, and with bytes flipped all over the scan
-    data = open(str(tmp_path / "opt.jpg"), "rb").read()
     rng = np.random.default_rng(3)
-    for k in range(24):
-        bad = bytearray(data[: len(data) - 1 - 40 * k] if k < 8 else data)
-        if k >= 8:
+    for k in range(48):
+        data = open(str(tmp_path / ("opt.jpg" if k % 2 == 0 else "prst.jpg")), "rb").read()
+        bad = bytearray(data[: len(data) - 1 - 20 * k] if k < 16 else data)
+        if k >= 16:
             for at in rng.integers(2, len(bad) - 2, size=1 + k // 4):
                 bad[int(at)] ^= int(rng.integers(1, 256))
         path = str(tmp_path / f"bad{k}.jpg")
@@ -345,8 +359,8 @@ def test_cpp_image_client_png_files(built, server, tmp_path, protocol, mode):
 
 def test_batch_image_decode_c_api(tmp_path):
     """``tca_decode_images`` behind ``ops.image_decode.decode_images``: a mixed batch (PNG of several colour
-    types, JPEG, PNM) decoded on native threads equals Pillow; what the native readers refuse (progressive
-    JPEG) falls back to Pillow; garbage is reported with the index of the file."""
+    types, JPEG, PNM) decoded on native threads equals Pillow; what the native readers refuse (a BMP file)
+    falls back to Pillow; garbage is reported with the index of the file."""
     import io
 
     import numpy as np
@@ -357,7 +371,7 @@ def test_batch_image_decode_c_api(tmp_path):
     rgb = _jpeg_photo(61, 83)
     blobs, want = [], []
     for fmt, kw in (("PNG", {}), ("JPEG", {"quality": 90}), ("JPEG", {"quality": 70, "subsampling": 0}), ("PPM", {}),
-                    ("JPEG", {"quality": 85, "progressive": True})):
+                    ("JPEG", {"quality": 85, "progressive": True}), ("BMP", {})):  # BMP: read by Pillow
         buf = io.BytesIO()
         Image.fromarray(rgb).save(buf, fmt, **kw)
         blobs.append(buf.getvalue())

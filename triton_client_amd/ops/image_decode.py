@@ -2,10 +2,10 @@
 
 The reference's server-side preprocessing decodes inside a DALI pipeline
 (``src/python/examples/ensemble_image_client.py:60-110`` feeds it raw file bytes); here the
-decoders of the C++ library (PNG on zlib, sequential JPEG with libjpeg's arithmetic, binary
-PNM - ``csrc/core/image_io.cc``, ``csrc/core/jpeg.cc``) run a whole batch side by side in one
+decoders of the C++ library (PNG on zlib, sequential and progressive JPEG with libjpeg's
+arithmetic, binary PNM - ``csrc/core/image_io.cc``, ``csrc/core/jpeg.cc``) run a whole batch side by side in one
 call that holds no interpreter lock, so concurrent requests of a Python model decode in
-parallel.  Files they do not read (progressive JPEG, GIF, ...) go to Pillow one by one."""
+parallel.  Files they do not read (GIF, BMP, CMYK JPEG, ...) go to Pillow one by one."""
 
 from __future__ import annotations
 
