@@ -227,7 +227,7 @@ PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
   int device = 0, max_batch = 0, max_inflight = 0, fill = 0, gap = 300, window = 100, split = 16, adaptive = 1;
   unsigned long long in_row = 0, out_row = 0, arena = 0, arena_bytes = 0, chunk_bytes = 0, device_arena = 0, copy_stream = 0,
                      memcpy_fn = 0;
-  if (!PyArg_ParseTuple(args, "sOiOOKKiiiiiip|KKKKKK", &name, &entry, &device, &streams, &graphs, &in_row, &out_row, &max_batch,
+  if (!PyArg_ParseTuple(args, "sOiOOKKiiiiiii|KKKKKK", &name, &entry, &device, &streams, &graphs, &in_row, &out_row, &max_batch,
                         &max_inflight, &fill, &gap, &window, &split, &adaptive, &arena, &arena_bytes, &chunk_bytes,
                         &device_arena, &copy_stream, &memcpy_fn))
     return nullptr;
@@ -276,7 +276,8 @@ PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
   p.burst_gap_us = gap;
   p.burst_window_us = window;
   p.split_min_batch = split;
-  p.adaptive_cap = adaptive != 0;
+  p.adaptive_cap = adaptive != 0;  // 0: off; 1: on with the default depth; n > 1: depth n / 10 batches per instance
+  if (adaptive > 1) p.cap_depth = adaptive / 10.0;
   if (arena != 0 && arena_bytes != 0 && chunk_bytes != 0) {
     p.host_arena = arena;
     p.host_arena_bytes = arena_bytes;

@@ -1361,7 +1361,7 @@ class NativeExecutor::GraphRunner {
         outstanding_peak_ = std::max(seen, outstanding_peak_ * 0.98);
         if (outstanding_peak_ <= 0.6 * 4 * pipe_.max_batch) {
           const int step = std::max(1, group[0]->batch);
-          const double per = outstanding_peak_ / (2.0 * static_cast<double>(instances_.size()));
+          const double per = outstanding_peak_ / (pipe_.cap_depth * static_cast<double>(instances_.size()));
           int c = static_cast<int>((static_cast<long long>(per + step - 1e-9) / step)) * step;
           cap = std::min(pipe_.max_batch, std::max(step, c));
         }

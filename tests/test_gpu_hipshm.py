@@ -277,8 +277,10 @@ def test_concurrent_clients_get_their_own_answers(hipshm, gpu_server):
     assert not errors, errors
     with mod.InferenceServerClient(gpu_server.grpc_url) as c:
         stats = c.get_inference_statistics("resnet50", as_json=True)["model_stats"][0]
-        # requests were merged: fewer executions than requests
-        assert int(stats["execution_count"]) < int(stats["inference_stats"]["success"]["count"])
+        # executions are merged batches: never more than requests (whether any two of these synchronous clients'
+        # requests met in the queue depends on timing; tests/test_gpu_native_graphs.py forces merging with 64
+        # requests at once and checks the batch counters)
+        assert 0 < int(stats["execution_count"]) <= int(stats["inference_stats"]["success"]["count"])
 
 
 @pytest.mark.parametrize("round_nearest", [False, True])

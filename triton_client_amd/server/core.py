@@ -808,7 +808,8 @@ class InferenceCore:
                 plan["out_row_bytes"], plan["max_batch"], int(os.environ.get("TCA_MAX_INFLIGHT_BATCHES", 0)) or int(
                     getattr(model, "max_inflight_batches", 2 * batcher.instances)),
                 int(batcher.fill_window_s * 1e6), int(batcher.burst_gap_s * 1e6), int(batcher.burst_window_s * 1e6),
-                int(batcher.split_min_batch), bool(batcher._adaptive_cap),
+                int(batcher.split_min_batch),
+                (max(2, int(round(10 * float(os.environ.get("TCA_ADAPTIVE_CAP_DEPTH", "2.0"))))) if batcher._adaptive_cap else 0),
                 int(arena.ptr) if arena else 0, int(arena.nbytes) if arena else 0, 256 << 10,
                 int(staged[0].data_ptr()) if staged else 0, int(staged[1].cuda_stream) if staged else 0,
                 address(lib.tca_hip_memcpy_async) if stage_mode == "sdma" else 0)
