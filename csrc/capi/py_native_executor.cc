@@ -217,7 +217,7 @@ PyObject* Quiesce(PyObject* self_obj, PyObject*) {
 
 // enable_graph_model(name, entry_points, device, streams, graphs, in_row_bytes, out_row_bytes, max_batch,
 //                    max_inflight, fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap
-//                    [, host_arena, host_arena_bytes, host_chunk_bytes[, device_arena, copy_stream[, memcpy_async]]])
+//                    [, host_arena, host_arena_bytes, host_chunk_bytes[, device_arena, copy_stream[, memcpy_async[, cap_limit_tenths]]]])
 // entry_points: addresses of (graph_launch, event_create, event_record, event_sync, event_destroy, set_device,
 // batched_copy); streams: one handle per execution instance; graphs: (instance, batch, exec, in_ptr, out_ptr).
 PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
@@ -227,9 +227,10 @@ PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
   int device = 0, max_batch = 0, max_inflight = 0, fill = 0, gap = 300, window = 100, split = 16, adaptive = 1;
   unsigned long long in_row = 0, out_row = 0, arena = 0, arena_bytes = 0, chunk_bytes = 0, device_arena = 0, copy_stream = 0,
                      memcpy_fn = 0;
-  if (!PyArg_ParseTuple(args, "sOiOOKKiiiiiii|KKKKKK", &name, &entry, &device, &streams, &graphs, &in_row, &out_row, &max_batch,
+  int cap_limit_tenths = 0;
+  if (!PyArg_ParseTuple(args, "sOiOOKKiiiiiii|KKKKKKi", &name, &entry, &device, &streams, &graphs, &in_row, &out_row, &max_batch,
                         &max_inflight, &fill, &gap, &window, &split, &adaptive, &arena, &arena_bytes, &chunk_bytes,
-                        &device_arena, &copy_stream, &memcpy_fn))
+                        &device_arena, &copy_stream, &memcpy_fn, &cap_limit_tenths))
     return nullptr;
   tca::server::NativeExecutor::GraphPipe p;
   unsigned long long fn[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -278,6 +279,7 @@ PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
   p.split_min_batch = split;
   p.adaptive_cap = adaptive != 0;  // 0: off; 1: on with the default depth; n > 1: depth n / 10 batches per instance
   if (adaptive > 1) p.cap_depth = adaptive / 10.0;
+  if (cap_limit_tenths > 0) p.cap_limit = cap_limit_tenths / 10.0;
   if (arena != 0 && arena_bytes != 0 && chunk_bytes != 0) {
     p.host_arena = arena;
     p.host_arena_bytes = arena_bytes;
@@ -397,7 +399,7 @@ PyMethodDef kMethods[] = {
     {"enable_graph_model", EnableGraphModel, METH_VARARGS,
      "enable_graph_model(name, entry_points, device, streams, graphs, in_row_bytes, out_row_bytes, max_batch, max_inflight, "
      "fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap[, host_arena, host_arena_bytes, "
-     "host_chunk_bytes[, device_arena, copy_stream[, memcpy_async]]]): page-locked memory for requests with tensors inside the messages, and "
+     "host_chunk_bytes[, device_arena, copy_stream[, memcpy_async[, cap_limit_tenths]]]]): page-locked memory for requests with tensors inside the messages, and "
      "device memory of the same size plus a stream for moving their inputs ahead of the batches"},
     {"disable_graph_model", DisableGraphModel, METH_VARARGS, "disable_graph_model([name]): answers what is queued and stops the threads"},
     {"begin_capture", BeginCapture, METH_NOARGS,

@@ -103,7 +103,9 @@ class NativeExecutor {
     int fill_window_us = 0, burst_gap_us = 300, burst_window_us = 100;
     int split_min_batch = 16;
     bool adaptive_cap = true;
-    double cap_depth = 2.0;  // with few images outstanding, merged batches are capped so that every instance gets this many
+    // With few images outstanding (at most cap_limit x max_batch, seen as a decaying peak) merged batches are capped so
+    // that every instance gets cap_depth of them; beyond the limit everything queued merges.
+    double cap_depth = 1.0, cap_limit = 0.8;
     // Requests whose tensors travel inside the messages: page-locked host memory that the device addresses too
     // (the gather / scatter kernels read and write it over the bus).  A request's input bytes are copied into
     // a piece of it by the thread that received the message, its output rows are taken from there into the

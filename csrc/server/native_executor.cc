@@ -1359,7 +1359,7 @@ class NativeExecutor::GraphRunner {
       if (pipe_.adaptive_cap) {
         const double seen = static_cast<double>(images_on_gpu_) + static_cast<double>(queue_.size() + 1) * group[0]->batch;
         outstanding_peak_ = std::max(seen, outstanding_peak_ * 0.98);
-        if (outstanding_peak_ <= 0.6 * 4 * pipe_.max_batch) {
+        if (outstanding_peak_ <= pipe_.cap_limit * pipe_.max_batch) {
           const int step = std::max(1, group[0]->batch);
           const double per = outstanding_peak_ / (pipe_.cap_depth * static_cast<double>(instances_.size()));
           int c = static_cast<int>((static_cast<long long>(per + step - 1e-9) / step)) * step;
