@@ -145,6 +145,15 @@ int main(int argc, char** argv) {
       if (pos != std::string::npos) name.replace(pos, 6, std::to_string(s));
       return name;
     };
+    // offsets: a number, or "<stride>*slot[+<base>]" for slots that share one region
+    auto slot_offset = [&](const std::string& text) -> uint64_t {
+      const size_t star = text.find("*slot");
+      if (star == std::string::npos) return std::strtoull(text.c_str(), nullptr, 10);
+      uint64_t off = std::strtoull(text.substr(0, star).c_str(), nullptr, 10) * static_cast<uint64_t>(s);
+      const size_t plus = text.find('+', star);
+      if (plus != std::string::npos) off += std::strtoull(text.substr(plus + 1).c_str(), nullptr, 10);
+      return off;
+    };
     for (const auto& spec : shapes) {
       auto parts = Split(spec, ':');
       if (parts.size() != 3) { std::cerr << "bad --shape " << spec << std::endl; return 2; }
@@ -179,7 +188,7 @@ int main(int argc, char** argv) {
       e = tc::InferInput::Create(&in, parts[0], Dims(parts[2]), parts[1]);
       if (!e.IsOk()) { std::cerr << e.Message() << std::endl; return 1; }
       in->SetSharedMemory(subst(parts[3]), std::strtoull(parts[4].c_str(), nullptr, 10),
-                          parts.size() > 5 ? std::strtoull(parts[5].c_str(), nullptr, 10) : 0);
+                          parts.size() > 5 ? slot_offset(parts[5]) : 0);
       slot->inputs.emplace_back(in);
       slot->in_ptrs.push_back(in);
     }
@@ -189,7 +198,7 @@ int main(int argc, char** argv) {
       tc::InferRequestedOutput* out = nullptr;
       tc::InferRequestedOutput::Create(&out, parts[0]);
       out->SetSharedMemory(subst(parts[1]), std::strtoull(parts[2].c_str(), nullptr, 10),
-                           parts.size() > 3 ? std::strtoull(parts[3].c_str(), nullptr, 10) : 0);
+                           parts.size() > 3 ? slot_offset(parts[3]) : 0);
       slot->outputs.emplace_back(out);
       slot->out_ptrs.push_back(out);
     }

@@ -1137,7 +1137,8 @@ struct NativeExecutor::GraphJob {
   std::shared_ptr<GraphRunner> runner;
   uint64_t host_ptr = 0, host_bytes = 0, host_out = 0, host_out_bytes = 0;
   uint8_t* sys_out = nullptr;  // output window in a system shared-memory region (held by req.held): filled from host_out
-  uint64_t stage_bytes = 0;    // input bytes in the host arena that the staging thread moves to the device arena
+  uint64_t stage_bytes = 0;    // input bytes the staging thread moves to the device arena ...
+  uint64_t stage_src = 0;      // ... from here (the request's piece of the host arena)
   uint64_t t_queued = 0;
   uint64_t gap_ns = ~0ull >> 2;  // since the previous arrival for this model
 };
@@ -1303,7 +1304,7 @@ class NativeExecutor::GraphRunner {
       dsts.clear();
       bytes.clear();
       for (auto& job : round) {
-        srcs.push_back(reinterpret_cast<const void*>(static_cast<uintptr_t>(job->host_ptr)));
+        srcs.push_back(reinterpret_cast<const void*>(static_cast<uintptr_t>(job->stage_src)));
         dsts.push_back(reinterpret_cast<void*>(static_cast<uintptr_t>(pipe_.device_arena + (job->host_ptr - pipe_.host_arena))));
         bytes.push_back(job->stage_bytes);
       }
@@ -1758,6 +1759,7 @@ bool NativeExecutor::PrepareGraphJob(Request* req, const std::shared_ptr<Model>&
       std::memcpy(reinterpret_cast<void*>(static_cast<uintptr_t>(job->host_ptr)), in_bytes, in_need);
       job->in_ptr = job->host_ptr;  // the staging thread, when there is one, points it at the device arena
       job->stage_bytes = in_need;
+      job->stage_src = job->host_ptr;
     }
     if (out_wire) {
       job->host_out = job->host_ptr + in_part;

@@ -25,7 +25,7 @@ except Exception:
 PY
     sleep 2
 done
-TCA_PERF_CONNECTIONS=8 timeout -k 10 120 python3 -m triton_client_amd.perf -m resnet50 -u 127.0.0.1:18201 -i grpc -b 8 --shared-memory ${SHM:-hip} \
+TCA_PERF_CONNECTIONS=8 timeout -k 10 120 python3 -m triton_client_amd.perf -m resnet50 -u 127.0.0.1:${PORT:-18201} -i ${PROTO:-grpc} -b 8 --shared-memory ${SHM:-hip} \
     --concurrency-range ${CONC:-64}:${CONC:-64} --native -p 1500 --stability-windows 2 > "$OUT/busy_perf.txt" 2>&1
 RC=$?
 kill $HOLD 2>/dev/null
