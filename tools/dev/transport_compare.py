@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 import urllib.request
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -62,14 +63,19 @@ with spawn_server(models=["resnet50"], gpu=0, env={k: v for k, v in os.environ.i
                     ("hipshm http", "http", srv.http_url, ["--shm-input", f"input:FP16:8,3,224,224:tin{{slot}}:{x.nbytes}",
                                                            "--shm-output", "output:tout{slot}:32000"])):
                 before = counters(srv)
+                t_before = time.perf_counter()
                 cmd = [LOADGEN, "-u", url, "-i", proto, "-m", "resnet50", "-c", c, "-b", "8", "--connections", "8", "-d", "2.5",
                        "--warmup", "0.8"] + extra
                 out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
                 r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
                 after = counters(srv)
+                wall = time.perf_counter() - t_before
                 d = {k.replace("tca_native_graph_", "").replace("_total", ""): after[k] - before.get(k, 0) for k in after}
                 print(json.dumps({"transport": name, "concurrency": int(c), "infer_per_sec": round(r["infer_per_sec"]),
                                   "p50_us": round(r["p50_us"]), "p99_us": round(r["p99_us"]), "errors": r["errors"],
+                                  "server_images_per_wall_second_incl_startup": round(d["images"] / wall) if False else None,
+                                  "server_images": int(after["tca_native_graph_images_total"] - before.get("tca_native_graph_images_total", 0)),
+                                  "generator_wall_s": round(wall, 2),
                                   "images_per_batch": round(d["images"] / max(1, d["batches"]), 1),
                                   "padded_share": round(d["padded_images"] / max(1, d["images"]), 3)}), flush=True)
     ctl.unregister_cuda_shared_memory()
