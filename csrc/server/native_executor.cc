@@ -1175,6 +1175,7 @@ class NativeExecutor::GraphRunner {
       (*job)->gap_ns = now - last_arrival_ns_;
       last_arrival_ns_ = now;
       if ((*job)->stage_bytes != 0 && stage_thread_.joinable()) {
+        images_staging_ += (*job)->batch;
         stage_queue_.push_back(std::move(*job));
         stage_cv_.notify_one();
         return true;
@@ -1299,6 +1300,8 @@ class NativeExecutor::GraphRunner {
         stage_queue_.pop_front();
       }
       staging_ += round.size();
+      long long round_images = 0;
+      for (const auto& job : round) round_images += job->batch;
       lk.unlock();
       srcs.clear();
       dsts.clear();
@@ -1324,11 +1327,13 @@ class NativeExecutor::GraphRunner {
         for (auto& job : round) owner_->FinishGraphJob(job.get(), false, 0, 0, 0, false);
         lk.lock();
         staging_ -= round.size();
+        images_staging_ -= round_images;
         if (queue_.empty() && running_ == 0 && stage_queue_.empty() && staging_ == 0) idle_cv_.notify_all();
         continue;
       }
       lk.lock();
       staging_ -= round.size();
+      images_staging_ -= round_images;
       for (auto& job : round) {
         job->in_ptr = pipe_.device_arena + (job->host_ptr - pipe_.host_arena);
         queue_.push_back(std::move(job));
@@ -1358,7 +1363,11 @@ class NativeExecutor::GraphRunner {
       bool have_slot = false;
       int cap = pipe_.max_batch;
       if (pipe_.adaptive_cap) {
-        const double seen = static_cast<double>(images_on_gpu_) + static_cast<double>(queue_.size() + 1) * group[0]->batch;
+        // everything the server holds: on the GPU, queued here, and on its way through the staging copy (left
+        // out, a load of large requests looks like a low-concurrency one as soon as its batches are small -
+        // and the cap then keeps them small)
+        const double seen = static_cast<double>(images_on_gpu_ + images_staging_) +
+                            static_cast<double>(queue_.size() + 1) * group[0]->batch;
         outstanding_peak_ = std::max(seen, outstanding_peak_ * 0.98);
         if (outstanding_peak_ <= pipe_.cap_limit * pipe_.max_batch) {
           const int step = std::max(1, group[0]->batch);
@@ -1553,6 +1562,7 @@ class NativeExecutor::GraphRunner {
   bool stop_ = false, completers_stop_ = false;
   int inflight_ = 0, cap_ = 2;
   long long images_on_gpu_ = 0;
+  long long images_staging_ = 0;  // in the staging queue or being copied
   double outstanding_peak_ = 0;
   uint64_t last_arrival_ns_ = 0, last_done_ns_ = 0;
   size_t last_done_requests_ = 1, running_ = 0;

@@ -75,7 +75,8 @@ def main():
                               "mode": mode, "per_request_us": {k: round((after[k] - before[k]) / max(1, after["n"] - before["n"]) / 1e3, 1)
                                                                for k in ("queue", "compute_input", "compute_infer", "compute_output")},
                               "images_per_batch": round(float(metrics.get("tca_native_graph_images_total", 0)) / max(1.0, float(
-                                  metrics.get("tca_native_graph_batches_total", 1))), 1)}), flush=True)
+                                  metrics.get("tca_native_graph_batches_total", 1))), 1),
+                              "counters_since_start": {k[len("tca_native_graph_"):]: float(v) for k, v in metrics.items()}}), flush=True)
 
 
 if __name__ == "__main__":
