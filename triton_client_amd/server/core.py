@@ -788,7 +788,7 @@ class InferenceCore:
                                [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.outputs], "graph")
             # page-locked memory for requests whose tensors travel inside the messages: the receiving thread
             # copies the input bytes in, the gather / scatter kernels address it over the bus
-            arena_mb = int(os.environ.get("TCA_NATIVE_WIRE_ARENA_MB", "768"))
+            arena_mb = int(os.environ.get("TCA_NATIVE_WIRE_ARENA_MB", "1536"))
             arena = _device.PinnedBuffer(arena_mb << 20) if arena_mb > 0 else None
             # ... and a staging thread moves them on to device memory on a stream of its own, ahead of the
             # batches, with the DMA engines (hipMemcpyAsync).  Measured with both tensors in system shared
