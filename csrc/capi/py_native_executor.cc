@@ -219,7 +219,7 @@ PyObject* Quiesce(PyObject* self_obj, PyObject*) {
 //                    max_inflight, fill_window_us, burst_gap_us, burst_window_us, split_min_batch, adaptive_cap
 //                    [, host_arena, host_arena_bytes, host_chunk_bytes[, device_arena, copy_stream[, memcpy_async[, cap_limit_tenths]]]])
 // entry_points: addresses of (graph_launch, event_create, event_record, event_sync, event_destroy, set_device,
-// batched_copy); streams: one handle per execution instance; graphs: (instance, batch, exec, in_ptr, out_ptr).
+// batched_copy[, stream_sync]); streams: one handle per execution instance; graphs: (instance, batch, exec, in_ptr, out_ptr).
 PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
   auto* self = reinterpret_cast<PyNativeExecutor*>(self_obj);
   const char* name = nullptr;
@@ -233,8 +233,8 @@ PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
                         &device_arena, &copy_stream, &memcpy_fn, &cap_limit_tenths))
     return nullptr;
   tca::server::NativeExecutor::GraphPipe p;
-  unsigned long long fn[7] = {0, 0, 0, 0, 0, 0, 0};
-  if (!PyArg_ParseTuple(entry, "KKKKKKK", &fn[0], &fn[1], &fn[2], &fn[3], &fn[4], &fn[5], &fn[6])) return nullptr;
+  unsigned long long fn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (!PyArg_ParseTuple(entry, "KKKKKKK|K", &fn[0], &fn[1], &fn[2], &fn[3], &fn[4], &fn[5], &fn[6], &fn[7])) return nullptr;
   p.graph_launch = reinterpret_cast<decltype(p.graph_launch)>(static_cast<uintptr_t>(fn[0]));
   p.event_create = reinterpret_cast<decltype(p.event_create)>(static_cast<uintptr_t>(fn[1]));
   p.event_record = reinterpret_cast<decltype(p.event_record)>(static_cast<uintptr_t>(fn[2]));
@@ -242,6 +242,7 @@ PyObject* EnableGraphModel(PyObject* self_obj, PyObject* args) {
   p.event_destroy = reinterpret_cast<decltype(p.event_destroy)>(static_cast<uintptr_t>(fn[4]));
   p.set_device = reinterpret_cast<decltype(p.set_device)>(static_cast<uintptr_t>(fn[5]));
   p.batched_copy = reinterpret_cast<decltype(p.batched_copy)>(static_cast<uintptr_t>(fn[6]));
+  p.stream_sync = reinterpret_cast<decltype(p.stream_sync)>(static_cast<uintptr_t>(fn[7]));
   PyObject* seq = PySequence_Fast(streams, "streams must be a sequence of handles");
   if (seq == nullptr) return nullptr;
   for (Py_ssize_t i = 0; i < PySequence_Fast_GET_SIZE(seq); ++i) {

@@ -42,6 +42,15 @@ int tca_hip_stream_sync(void* stream) {
   return 0;
 }
 
+// 0: everything queued on the stream has completed, 1: not yet.  (Like a synchronisation, a query that finds
+// the stream drained lets the runtime release the bookkeeping of the commands behind it.)
+int tca_hip_stream_query(void* stream) {
+  const hipError_t e = hipStreamQuery(static_cast<hipStream_t>(stream));
+  if (e == hipErrorNotReady) return 1;
+  RT_TRY(e, "hipStreamQuery");
+  return 0;
+}
+
 int tca_hip_stream_destroy(void* stream) {
   RT_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)), "hipStreamDestroy");
   return 0;

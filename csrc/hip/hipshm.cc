@@ -76,6 +76,7 @@ struct DeviceCtx {
   size_t pinned_size = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};
   std::mutex mu;
+  uint64_t waits = 0;  // completed WaitEvent calls on this engine (under mu)
 };
 
 constexpr size_t kStageBytes = 8u << 20;       // per half of the ring, first engine of a device (bulk copies)
@@ -174,6 +175,16 @@ int WaitEvent(hipEvent_t ev, bool small) {
   return 0;
 }
 
+// The last wait of a staged copy: the engine's stream is idle afterwards.  Every 64th time the stream itself is
+// synchronised - the runtime keeps about a kilobyte per host-to-device hipMemcpyAsync until then, whatever
+// events were waited for.
+int WaitLast(DeviceCtx* ctx, hipEvent_t ev, bool small) {
+  if (int rc = WaitEvent(ev, small)) return rc;
+  if ((++ctx->waits & 63) == 0) HIP_TRY(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+  return 0;
+}
+
+
 struct Region {
   std::string name;
   void* ptr = nullptr;
@@ -232,7 +243,7 @@ int StagedH2D(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
     n -= chunk;
     slot ^= 1;
   }
-  return WaitEvent(ctx->ev[slot ^ 1], small);  // the event of the last chunk: the stream is in order
+  return WaitLast(ctx, ctx->ev[slot ^ 1], small);  // the event of the last chunk: the stream is in order
 }
 
 int StagedD2H(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
@@ -430,7 +441,7 @@ int tca_hipshm_read_many(int count, void* const* handles, const uint64_t* offset
     cursor += (sizes[i] + 63) & ~63ull;
   }
   HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
-  rc = WaitEvent(ctx->ev[0], total <= kSpinBytes);
+  rc = WaitLast(ctx, ctx->ev[0], total <= kSpinBytes);
   if (rc) return rc;
   cursor = 0;
   for (int i = 0; i < count; ++i) {
@@ -478,7 +489,7 @@ int tca_hipshm_write_many(int count, void* const* handles, const uint64_t* offse
     cursor += (sizes[i] + 63) & ~63ull;
   }
   HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream), "hipEventRecord");
-  return WaitEvent(ctx->ev[0], total <= kSpinBytes);
+  return WaitLast(ctx, ctx->ev[0], total <= kSpinBytes);
 }
 
 // Any address the runtime can classify (device, pinned host, peer device) ->

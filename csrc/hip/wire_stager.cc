@@ -148,7 +148,7 @@ struct Stager {
   bool dev_used[2] = {false, false};
   hipEvent_t landed = nullptr;
   int next = 0;
-  uint64_t staged_bytes = 0, staged_tensors = 0, ring_waits = 0;
+  uint64_t staged_bytes = 0, staged_tensors = 0, ring_waits = 0, stage_calls = 0;
   CopyPool pool{HelperThreads()};
 
   int FreeRing() {
@@ -255,6 +255,10 @@ int tca_stager_stage(void* handle, int count, const void* const* srcs, const uin
     const int rc = s->AllocDevice(extent);
     if (rc != 0) return rc;
   }
+  // The runtime keeps about a kilobyte per host-to-device hipMemcpyAsync until the stream itself is synchronised
+  // (the events below do not release it): drain the copy stream now and then - the previous upload has long
+  // landed, its batch has been running since.
+  if ((++s->stage_calls & 31) == 0) ST_TRY(hipStreamSynchronize(s->copy_stream), "hipStreamSynchronize");
   const int slot = s->next;
   s->next ^= 1;
   uint8_t* dev = s->dev[slot];

@@ -1323,6 +1323,9 @@ class NativeExecutor::GraphRunner {
       if (rc == 0) rc = pipe_.event_record(stage_event_, pipe_.copy_stream);
       owner_->LeaveLaunch();
       if (rc == 0) rc = pipe_.event_sync(stage_event_);
+      // the stream is idle here: every 16th round a synchronisation of the stream itself, which is what makes
+      // the runtime let go of its per-copy bookkeeping
+      if (rc == 0 && pipe_.stream_sync != nullptr && (++stage_rounds_ & 15) == 0) rc = pipe_.stream_sync(pipe_.copy_stream);
       if (rc != 0) {  // the requests take the general path
         for (auto& job : round) owner_->FinishGraphJob(job.get(), false, 0, 0, 0, false);
         lk.lock();
@@ -1563,6 +1566,7 @@ class NativeExecutor::GraphRunner {
   int inflight_ = 0, cap_ = 2;
   long long images_on_gpu_ = 0;
   long long images_staging_ = 0;  // in the staging queue or being copied
+  uint64_t stage_rounds_ = 0;     // staging thread only
   double outstanding_peak_ = 0;
   uint64_t last_arrival_ns_ = 0, last_done_ns_ = 0;
   size_t last_done_requests_ = 1, running_ = 0;

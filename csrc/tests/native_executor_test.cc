@@ -526,6 +526,17 @@ int FakeEventSync(void* event) {
   e->cv.wait(lk, [&] { return e->reached >= want; });
   return 0;
 }
+// the staging thread's periodic drain: by contract the stream has nothing queued when it is called (it follows
+// a wait for the event behind the round's copies)
+std::atomic<int> g_stream_syncs{0};
+std::atomic<int> g_stream_syncs_busy{0};
+int FakeStreamSync(void* stream) {
+  auto* s = static_cast<FakeStream*>(stream);
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (!s->work.empty()) g_stream_syncs_busy.fetch_add(1);
+  g_stream_syncs.fetch_add(1);
+  return 0;
+}
 int FakeEventDestroy(void* event) {
   delete static_cast<FakeEvent*>(event);
   return 0;
@@ -630,6 +641,7 @@ void GraphPath() {
   pipe.event_sync = FakeEventSync;
   pipe.event_destroy = FakeEventDestroy;
   pipe.batched_copy = FakeBatchedCopy;
+  pipe.stream_sync = FakeStreamSync;
   pipe.streams = {&streams[0], &streams[1]};
   pipe.in_row_bytes = 16;
   pipe.out_row_bytes = 8;
@@ -815,6 +827,8 @@ void GraphPath() {
   shm_unlink(sys_key);
   if (wire_answers.load() == 0 || counters.wire_requests < static_cast<uint64_t>(wire_answers.load()) || counters.arena_full == 0)
     Fail("graph: requests with tensors inside the messages were not served, or the staging memory never ran out");
+  if (g_stream_syncs.load() == 0 || g_stream_syncs_busy.load() != 0)
+    Fail("graph: the staging thread never drained its copy stream, or drained it with copies still queued");
   // a request queued while the model goes away is answered or handed back, never dropped
   {
     std::atomic<int> verdicts{0};

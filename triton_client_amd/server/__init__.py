@@ -24,6 +24,30 @@ import time
 from .core import InferenceCore, ServerError  # noqa: F401
 
 
+_arenas_limited = False
+
+
+def _limit_malloc_arenas():
+    """Caps the number of glibc malloc arenas of this process (``TCA_MALLOC_ARENAS``, default 8; 0 leaves the
+    allocator alone).  Message bodies of megabytes are allocated on a reactor thread and freed on a completer
+    thread; whenever a thread finds its arena locked glibc moves it to another one - up to eight per CPU core -
+    and every arena keeps the large blocks that were freed into it.  On a machine with hundreds of cores the
+    resident set of a server that receives 4.8 MB requests grew by 16 MB per second without end
+    (``tools/dev/soak.py``); with the cap it levels off."""
+    global _arenas_limited
+    if _arenas_limited:
+        return
+    _arenas_limited = True
+    try:
+        n = int(os.environ.get("TCA_MALLOC_ARENAS", "8"))
+        if n > 0 and "MALLOC_ARENA_MAX" not in os.environ:
+            import ctypes
+
+            ctypes.CDLL(None).mallopt(-8, n)  # M_ARENA_MAX
+    except Exception:  # noqa: BLE001 - another C library: nothing to cap
+        pass
+
+
 class Server:
     """In-process server.  ``http_port`` / ``grpc_port`` of 0 pick free ports."""
 
@@ -31,6 +55,7 @@ class Server:
                  enable_http=True, enable_grpc=True, http_workers=16, grpc_workers=32, grpc_impl=None,
                  tls_cert=None, tls_key=None, tls_client_ca=None, grpc_reactors=None, http_impl=None,
                  http_reactors=None, native_exec=None):
+        _limit_malloc_arenas()
         self.core = InferenceCore(models=models, gpu=gpu, model_control=model_control)
         self.host = host
         self._http_port = http_port

@@ -782,7 +782,7 @@ class InferenceCore:
             address = lambda fn: ctypes.cast(fn, ctypes.c_void_p).value  # noqa: E731
             entry_points = tuple(address(getattr(lib, fn)) for fn in (
                 "tca_hip_graph_launch", "tca_hip_event_create", "tca_hip_event_record", "tca_hip_event_sync",
-                "tca_hip_event_destroy", "tca_hip_set_device", "tca_batched_copy_launch"))
+                "tca_hip_event_destroy", "tca_hip_set_device", "tca_batched_copy_launch", "tca_hip_stream_sync"))
             executor.set_model(name, model.versions[-1], int(model.max_batch_size),
                                [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.inputs],
                                [(t.name, t.datatype, [int(d) for d in t.dims]) for t in model.outputs], "graph")
