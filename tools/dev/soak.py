@@ -4,7 +4,7 @@ memory, 64 in flight, in consecutive windows; per window throughput, p50 / p99, 
 size, its open file descriptors and the GPU memory in use.  A server that leaks, fragments its pools or slows
 down over time shows here.
 
-    python tools/dev/soak.py [windows=12] [seconds per window=10] [mode=hipshm|wire|system]
+    python tools/dev/soak.py [windows=12] [seconds per window=10] [mode=hipshm|wire|system|ensemble]
 """
 import json
 import os
@@ -28,7 +28,63 @@ def gpu_used_mb():
         return None
 
 
+def ensemble(windows, seconds):
+    """``preprocess_resnet50_ensemble``: eight 224x224 PNG files per request over gRPC from 24 client threads."""
+    import io
+    import threading
+    import time
+
+    import numpy as np
+    import psutil
+    import tritonclient.grpc as grpcclient
+    from PIL import Image
+
+    rng = np.random.default_rng(0)
+    blobs = []
+    for _ in range(8):
+        buf = io.BytesIO()
+        Image.fromarray((rng.random((224, 224, 3)) * 255).astype(np.uint8)).save(buf, "PNG", compress_level=3)
+        blobs.append(buf.getvalue())
+    with spawn_server(models=["resnet50", "preprocess_resnet50_ensemble"], gpu=0,
+                      env={k: v for k, v in os.environ.items() if k.startswith("TCA_")}) as srv:
+        server = psutil.Process(srv.proc.pid)
+        print(f"ensemble (8 PNG files per request), 24 client threads, {windows} windows of {seconds:.0f} s", flush=True)
+        print(f"{'window':>6s} {'img/s':>9s} {'errors':>6s} {'server RSS MB':>14s} {'fds':>5s} {'threads':>7s}", flush=True)
+        stop = threading.Event()
+        counts = [0] * 24
+        errors = [0] * 24
+
+        def worker(i):
+            c = grpcclient.InferenceServerClient(srv.grpc_url)
+            inp = grpcclient.InferInput("INPUT", [8, 1], "BYTES")
+            inp.set_data_from_numpy(np.array(blobs, dtype=np.object_).reshape(8, 1))
+            out = [grpcclient.InferRequestedOutput("OUTPUT", class_count=3)]
+            while not stop.is_set():
+                try:
+                    c.infer("preprocess_resnet50_ensemble", [inp], outputs=out)
+                    counts[i] += 1
+                except Exception:  # noqa: BLE001 - counted
+                    errors[i] += 1
+            c.close()
+
+        threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(24)]
+        for t in threads:
+            t.start()
+        last = 0
+        for w in range(windows):
+            time.sleep(seconds)
+            now = sum(counts)
+            print(f"{w:6d} {8 * (now - last) / seconds:9.0f} {sum(errors):6d} {server.memory_info().rss / 2 ** 20:14.0f} "
+                  f"{server.num_fds():5d} {server.num_threads():7d}", flush=True)
+            last = now
+        stop.set()
+        for t in threads:
+            t.join(timeout=30)
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "ensemble":
+        return ensemble(int(sys.argv[1]), float(sys.argv[2]))
     import numpy as np
     import psutil
     import tritonclient.grpc as grpcclient
