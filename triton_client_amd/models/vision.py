@@ -308,7 +308,20 @@ class ResNet50(Model):
         self._io_buffers = {}
         self._graph_pools = [None] * len(getattr(self, "_graph_pools", []))
         self._net = None
+        # the flattened weights, the packed stem and the per-stream workspaces go with the model
+        self._plan = None
+        self._proj, self._rows_w2, self._stem_packed = {}, {}, None
         if self._torch is not None:
+            from ..ops import conv
+
+            streams = list(getattr(self, "_streams", [])) + [getattr(self, "_side_stream", None)]
+            for st in streams:
+                if st is not None:
+                    st.synchronize()
+            conv.release_splitk_workspaces(self._device, [st for st in streams if st is not None])
+            import gc
+
+            gc.collect()  # captured graphs sit in reference cycles (closures over their static tensors)
             self._torch.cuda.empty_cache()
 
     # -- execution --

@@ -48,6 +48,12 @@ class Stream:
             lib().tca_hip_stream_destroy(self.handle)
             self.handle = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
 
 class DeviceBuffer:
     def __init__(self, nbytes, device=0):

@@ -81,6 +81,13 @@ def _splitk_workspace(device):
     return ws
 
 
+def release_splitk_workspaces(device, streams):
+    """Drops the split-K workspaces of ``streams`` (torch streams of ``device``): a model that is unloaded takes
+    its streams with it, and their workspaces (32 MiB each) would otherwise stay for the life of the process."""
+    for st in streams:
+        _splitk_workspaces.pop((device.index, st.cuda_stream), None)
+
+
 _tuning = None
 
 
