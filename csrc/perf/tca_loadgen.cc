@@ -13,7 +13,8 @@
 //                            reactor thread and a connection pool each) (default 1)
 //       --trace FILE         write one CSV row per measured request:
 //                            start_ns (since the measured phase began), latency_ns, slot, ok
-//       --shape NAME:DATATYPE:d0,d1,...      wire tensors (zero filled)
+//       --shape NAME:DATATYPE:d0,d1,...      wire tensors (floating-point types: pseudo-random finite values,
+//                                            --wire-data zero for zeros; other types zero filled)
 //       --shm-input NAME:DATATYPE:dims:REGION:BYTES[:OFFSET]   registered shm input
 //       --shm-output NAME:REGION:BYTES[:OFFSET]
 //       --streaming          gRPC: requests travel on one bidirectional stream per connection
@@ -87,6 +88,7 @@ int main(int argc, char** argv) {
   uint64_t sequence_id_base = 1;
   double duration = 5.0, warmup = 1.0;
   std::vector<std::string> shapes, shm_in, shm_out;
+  bool wire_random = true;  // --wire-data zero|random
   std::string trace_path;
   for (int i = 1; i < argc; ++i) {
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -107,6 +109,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "-d")) duration = std::atof(next());
     else if (!std::strcmp(argv[i], "--warmup")) warmup = std::atof(next());
     else if (!std::strcmp(argv[i], "--shape")) shapes.push_back(next());
+    else if (!std::strcmp(argv[i], "--wire-data")) wire_random = std::strcmp(next(), "zero") != 0;
     else if (!std::strcmp(argv[i], "--shm-input")) shm_in.push_back(next());
     else if (!std::strcmp(argv[i], "--shm-output")) shm_out.push_back(next());
     else { std::cerr << "unknown argument " << argv[i] << std::endl; return 2; }
@@ -176,6 +179,36 @@ int main(int argc, char** argv) {
         slot->storage.push_back(std::move(packed));
       } else {
         slot->storage.emplace_back(bytes, 0);
+        // Floating-point tensors carry finite pseudo-random values of magnitude 1/8 ... 2 and either sign (a model
+        // fed zeros does less switching work: ResNet-50 on an MI355X then runs at 2.39 GHz instead of 2.09 and 6 %
+        // faster, which says nothing about real inputs); integer tensors stay zero - models read delays, counts
+        // and indices from them.
+        if (wire_random && (parts[1] == "FP16" || parts[1] == "BF16" || parts[1] == "FP32")) {
+          uint64_t state = 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(s + 1) + slot->storage.size();
+          auto next = [&state]() {
+            state ^= state << 13;
+            state ^= state >> 7;
+            state ^= state << 17;
+            return state;
+          };
+          uint8_t* p = slot->storage.back().data();
+          if (parts[1] == "FP32") {
+            for (int64_t k = 0; k < count; ++k) {
+              const uint64_t r = next();
+              const uint32_t v = (static_cast<uint32_t>(r & 1) << 31) | ((124u + static_cast<uint32_t>((r >> 1) & 3)) << 23) |
+                                 static_cast<uint32_t>((r >> 8) & 0x7FFFFF);
+              std::memcpy(p + 4 * k, &v, 4);
+            }
+          } else {
+            const bool bf16 = parts[1] == "BF16";
+            for (int64_t k = 0; k < count; ++k) {
+              const uint64_t r = next();
+              const uint16_t v = bf16 ? static_cast<uint16_t>(((r & 1) << 15) | ((124u + ((r >> 1) & 3)) << 7) | ((r >> 8) & 0x7F))
+                                      : static_cast<uint16_t>(((r & 1) << 15) | ((12u + ((r >> 1) & 3)) << 10) | ((r >> 8) & 0x3FF));
+              std::memcpy(p + 2 * k, &v, 2);
+            }
+          }
+        }
       }
       in->AppendRaw(slot->storage.back().data(), bytes);
       slot->inputs.emplace_back(in);

@@ -1371,7 +1371,16 @@ class NativeExecutor::GraphRunner {
         // and the cap then keeps them small)
         const double seen = static_cast<double>(images_on_gpu_ + images_staging_) +
                             static_cast<double>(queue_.size() + 1) * group[0]->batch;
-        outstanding_peak_ = std::max(seen, outstanding_peak_ * 0.98);
+        // the largest count of the recent past: it gives way by a tenth per 300 ms, not per batch - a load of large
+        // requests holds few images at the server between its bursts, and a peak that forgot the bursts within
+        // 25 ms let the cap flap on and off under it (64 in flight on the wire: 63k with the cap flapping, 70k without)
+        if (seen >= outstanding_peak_) {
+          outstanding_peak_ = seen;
+          peak_time_ = t_first;
+        } else if (t_first - peak_time_ > std::chrono::milliseconds(300)) {
+          outstanding_peak_ = std::max(seen, outstanding_peak_ * 0.9);
+          peak_time_ = t_first;
+        }
         if (outstanding_peak_ <= pipe_.cap_limit * pipe_.max_batch) {
           const int step = std::max(1, group[0]->batch);
           const double per = outstanding_peak_ / (pipe_.cap_depth * static_cast<double>(instances_.size()));
@@ -1568,6 +1577,7 @@ class NativeExecutor::GraphRunner {
   long long images_staging_ = 0;  // in the staging queue or being copied
   uint64_t stage_rounds_ = 0;     // staging thread only
   double outstanding_peak_ = 0;
+  Clock::time_point peak_time_{};
   uint64_t last_arrival_ns_ = 0, last_done_ns_ = 0;
   size_t last_done_requests_ = 1, running_ = 0;
   GraphCounters counters_;
