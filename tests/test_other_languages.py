@@ -94,3 +94,24 @@ def test_java_binary_protocol_matches_python_codec():
     assert packed == b"\x02\x00\x00\x00ab\x00\x00\x00\x00\x03\x00\x00\x00xyz"
     text = open(os.path.join(JAVA_ROOT, "tca", "client", "BinaryProtocol.java")).read()
     assert "ByteOrder.LITTLE_ENDIAN" in text and "putInt(e.length)" in text
+
+
+def test_java_api_build_script_options_and_refusals():
+    """``src/java-api-bindings/scripts/install_dependencies_and_build.sh`` (the reference's script of that name builds
+    JavaCPP bindings of the server's C API, ``src/java-api-bindings/scripts/install_dependencies_and_build.sh:27-41``;
+    ours packages the client API): parses, documents its options, refuses unknown ones, and without a JDK says so
+    instead of downloading one.  Parity of the build itself is unpinned here: no JDK in this image."""
+    import shutil
+    import subprocess
+
+    script = os.path.join(ROOT, "src", "java-api-bindings", "scripts", "install_dependencies_and_build.sh")
+    assert subprocess.run(["bash", "-n", script]).returncode == 0
+    usage = subprocess.run([script, "--help"], capture_output=True, text=True)
+    assert usage.returncode == 0
+    for option in ("--build-home", "--maven-version", "--jar-install-path", "--offline", "--keep-build-dependencies"):
+        assert option in usage.stdout
+    bad = subprocess.run([script, "--no-such-option"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "unknown option" in bad.stderr
+    if shutil.which("javac") is None:
+        run = subprocess.run([script, "--offline"], capture_output=True, text=True)
+        assert run.returncode == 3 and "JDK" in run.stderr
