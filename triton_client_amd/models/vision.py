@@ -314,7 +314,9 @@ class ResNet50(Model):
         if self._torch is not None:
             from ..ops import conv
 
-            streams = list(getattr(self, "_streams", [])) + [getattr(self, "_side_stream", None)]
+            streams = (list(getattr(self, "_streams", [])) + [getattr(self, "_side_stream", None)]
+                       + list(getattr(self, "_plan_streams", [])))
+            self._plan_streams = []
             for st in streams:
                 if st is not None:
                     st.synchronize()
@@ -322,6 +324,11 @@ class ResNet50(Model):
             import gc
 
             gc.collect()  # captured graphs sit in reference cycles (closures over their static tensors)
+            # PyTorch keeps one BLAS workspace (76 MiB on this GPU) per stream that ever ran a library GEMM - the
+            # eager warm-up does, on a stream that goes with the model
+            clear = getattr(self._torch._C, "_cuda_clearCublasWorkspaces", None)
+            if clear is not None:
+                clear()
             self._torch.cuda.empty_cache()
 
     # -- execution --
@@ -640,6 +647,7 @@ class ResNet50(Model):
                 graphs.append((inst, b, int(g.raw_cuda_graph_exec()), int(x.data_ptr()), int(out.data_ptr())))
                 keep.append((g, x, out))
         keep.append((streams, pools))
+        self._plan_streams = getattr(self, "_plan_streams", []) + streams  # unload() drops their workspaces
         return {"graphs": graphs, "keep": keep, "streams": [int(s.cuda_stream) for s in streams],
                 "in_row_bytes": int(keep[0][1][0].numel() * keep[0][1].element_size()),
                 "out_row_bytes": int(keep[0][2][0].numel() * 4), "max_batch": int(self.max_batch_size)}
