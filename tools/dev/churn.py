@@ -89,6 +89,42 @@ def main():
                 ctl.unload_model(m)
                 ctl.load_model(m)
             report("300 abandoned sequences + every model reloaded", r)
+        if args.gpu is not None:
+            # a load generator killed in mid-flight, four times over, then a clean run on the same regions
+            import json
+            import signal
+            import subprocess
+            import time
+
+            import tritonclient.utils.cuda_shared_memory as hipshm
+
+            loadgen = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                                   "triton_client_amd", "_lib", "tca_loadgen")
+            x = np.random.default_rng(0).standard_normal((8, 3, 224, 224)).astype(np.float16)
+            regions = []
+            for i in range(64):
+                hin = hipshm.create_shared_memory_region(f"kin{i}", x.nbytes, args.gpu)
+                hout = hipshm.create_shared_memory_region(f"kout{i}", 32000, args.gpu)
+                hipshm.set_shared_memory_region(hin, [x])
+                ctl.register_cuda_shared_memory(f"kin{i}", hipshm.get_raw_handle(hin), args.gpu, x.nbytes)
+                ctl.register_cuda_shared_memory(f"kout{i}", hipshm.get_raw_handle(hout), args.gpu, 32000)
+                regions += [hin, hout]
+            cmd = [loadgen, "-u", srv.grpc_url, "-i", "grpc", "-m", "resnet50", "-c", "64", "-b", "8", "--connections", "8",
+                   "--shm-input", f"input:FP16:8,3,224,224:kin{{slot}}:{x.nbytes}", "--shm-output", "output:kout{slot}:32000"]
+            for r in range(4):
+                p = subprocess.Popen(cmd + ["-d", "30", "--warmup", "0.2"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                time.sleep(2.5)
+                p.send_signal(signal.SIGKILL)
+                p.wait()
+                time.sleep(0.5)
+                report("load generator killed with 64 requests in flight", r)
+            out = subprocess.run(cmd + ["-d", "3", "--warmup", "0.5"], capture_output=True, text=True, timeout=120)
+            res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+            print(f"clean run afterwards: {res['infer_per_sec']:.0f} infer/s, {res['errors']} errors", flush=True)
+            ctl.unregister_cuda_shared_memory()
+            for h in regions:
+                hipshm.destroy_shared_memory_region(h)
+            report("regions unregistered", 0)
         ctl.close()
 
 
