@@ -39,6 +39,10 @@ def main():
                     help="also try every tile with two and with three LDS stages (measured: the table it gives was "
                          "1.5 %% slower under the headline load than the one without)")
     ap.add_argument("--wide", action="store_true", help="also try the 256-wide and 16-wavefront tiles")
+    ap.add_argument("--sustain", type=float, default=0.0,
+                    help="seconds every candidate is replayed for (with --streams > 1); only the second half is timed.  "
+                         "Under a sustained load the GPU is power-limited (2.1 instead of 2.4 GHz under the serving load): "
+                         "what a tile costs then includes what its energy does to the clock")
     args = ap.parse_args()
     variants = VARIANTS + (WIDE_VARIANTS if args.wide else ())
     import torch
@@ -68,13 +72,30 @@ def main():
                 g.replay()
                 st.synchronize()
                 graphs.append(g)
+        def replay_all():
+            for st, g in zip(streams, graphs):
+                with torch.cuda.stream(st):
+                    g.replay()
+
+        if args.sustain > 0:
+            # first half: the clock settles; second half: timed.  A synchronisation every 20 rounds keeps the
+            # launch queue short without draining the GPU for long.
+            for timed in (False, True):
+                rounds = 0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < args.sustain / 2:
+                    for _ in range(20):
+                        replay_all()
+                    rounds += 20
+                    torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t0
+            return elapsed * 1e6 / (rounds * args.reps * len(streams))
         rounds = 6
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(rounds):
-            for st, g in zip(streams, graphs):
-                with torch.cuda.stream(st):
-                    g.replay()
+            replay_all()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1e6 / (rounds * args.reps * len(streams))
 

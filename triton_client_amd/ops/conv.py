@@ -100,7 +100,9 @@ def tuning_table():
         import json
         import os
 
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning_gfx950.json")
+        # TCA_CONV_TUNING_FILE: another table (A/B runs of a freshly tuned one)
+        path = os.environ.get("TCA_CONV_TUNING_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                      "conv_tuning_gfx950.json")
         table = {"conv": {}, "fused": {}}
         if os.environ.get("TCA_CONV_TUNING", "1") != "0" and os.path.exists(path):
             with open(path) as fh:
