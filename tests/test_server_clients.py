@@ -742,3 +742,31 @@ def test_http_front_protocol_edges(impl):
             out = _raw_http(port, b"NONSENSE\r\n\r\n", expect_close=True)
             assert out.startswith(b"HTTP/1.1 400")
             assert srv.http.stats()["requests"] >= 6
+
+
+def test_malloc_arena_cap_is_applied_once_and_can_be_turned_off():
+    """The server caps glibc's malloc arenas (message bodies of megabytes are allocated on reactor threads and
+    freed on completer threads); ``TCA_MALLOC_ARENAS=0`` leaves the allocator alone."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import ctypes\n"
+        "calls = []\n"
+        "import triton_client_amd.server as srv\n"
+        "real = ctypes.CDLL\n"
+        "class Fake:\n"
+        "    def mallopt(self, what, value):\n"
+        "        calls.append((what, value)); return 1\n"
+        "ctypes.CDLL = lambda *a, **k: Fake()\n"
+        "srv._limit_malloc_arenas(); srv._limit_malloc_arenas()\n"
+        "print('CALLS', calls)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    on = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                        env={k: v for k, v in os.environ.items() if k not in ("TCA_MALLOC_ARENAS", "MALLOC_ARENA_MAX")})
+    assert "CALLS [(-8, 8)]" in on.stdout, on.stdout + on.stderr
+    off = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, TCA_MALLOC_ARENAS="0"))
+    assert "CALLS []" in off.stdout, off.stdout + off.stderr
