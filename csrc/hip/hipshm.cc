@@ -271,6 +271,8 @@ int StagedD2H(DeviceCtx* ctx, void* dst, const void* src, size_t n) {
     tail ^= 1;
     --inflight;
   }
+  // device-to-host copies accumulate runtime bookkeeping like host-to-device ones (see WaitLast)
+  if ((++ctx->waits & 63) == 0) HIP_TRY(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
   return 0;
 }
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Resident set size of a process that does nothing but hipMemcpyAsync (page-locked host memory -> device) on one
 stream, waiting for each round of 8 copies through an event - the native executor's staging loop in isolation -
-and the same with a hipStreamSynchronize per round, and with device-to-device copies."""
+and the same with a hipStreamSynchronize per round or every 64 rounds, with device-to-device and with
+device-to-host copies."""
 import ctypes
 import os
 import sys
@@ -26,11 +27,15 @@ def main():
     _device.check(L.tca_hip_event_create(ctypes.byref(event)), "event")
     piece = 2408448  # one batch-8 request
     slots = nbytes // piece
-    for label, kind, src, sync_stream in (("H2D, event sync only", 1, host, 0), ("H2D, + stream QUERY per round", 1, host, -1),
+    # "d2h" / "d2d" as the first argument: only that kind, in a fresh process (nothing freed earlier to grow into)
+    only = {"d2h": ("D2H, event sync only", 2, dev2, 0), "d2d": ("D2D, event sync only", 3, dev2, 0)}.get(
+        sys.argv[1] if len(sys.argv) > 1 else "")
+    for label, kind, src, sync_stream in ((only,) * 2) if only else (("H2D, event sync only", 1, host, 0), ("H2D, + stream QUERY per round", 1, host, -1),
                                           ("H2D, event sync only (again)", 1, host, 0),
                                           ("H2D, + stream sync every 64 rounds", 1, host, 64),
                                           ("H2D, event sync only (again)", 1, host, 0),
-                                          ("H2D, + stream sync per round", 1, host, 1), ("D2D, event sync only", 3, dev2, 0)):
+                                          ("H2D, + stream sync per round", 1, host, 1), ("D2D, event sync only", 3, dev2, 0),
+                                          ("D2H, event sync only", 2, dev2, 0), ("D2H, + stream sync every 64 rounds", 2, dev2, 64)):
         t0 = time.time()
         calls = 0
         print(f"{label}: RSS {me.memory_info().rss / 2 ** 20:.0f} MB at start", flush=True)
@@ -40,7 +45,8 @@ def main():
                 for _ in range(20):
                     for i in range(8):
                         off = ((calls + i) % slots) * piece
-                        L.tca_hip_memcpy_async(vp(dev.value + off), vp(src.value + off), ctypes.c_uint64(piece), kind, stream)
+                        dst = host if kind == 2 else dev
+                        L.tca_hip_memcpy_async(vp(dst.value + off), vp(src.value + off), ctypes.c_uint64(piece), kind, stream)
                     L.tca_hip_event_record(event, stream)
                     L.tca_hip_event_sync(event)
                     calls += 8

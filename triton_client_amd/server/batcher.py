@@ -597,6 +597,7 @@ class DynamicBatcher:
         import torch
 
         torch.cuda.set_device(self.lm.device_index or 0)
+        drained = 0
         while True:
             entry = self.completions[inst].get()
             if entry is None:
@@ -634,6 +635,12 @@ class DynamicBatcher:
                 except Exception as e:
                     it.error = ServerError(f"internal error: {type(e).__name__}: {e}", 500)
                 it.finish()
+            # The HIP runtime keeps about a kilobyte per asynchronous host<->device copy until the STREAM is
+            # synchronised; the event waits above do not release it.  After the answers are out, every 64th batch:
+            # the wait is for the batch this loop would wait for next anyway.
+            drained += 1
+            if drained % 64 == 0:
+                self._stream_of(inst).synchronize()
 
     def _respond(self, it, final, requested, out_specs, dev_inputs):
         from .core import InferResponse, OutputTensor, PackedBytes
